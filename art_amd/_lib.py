@@ -1,0 +1,102 @@
+"""ctypes binding of libartmips.so (C ABI: include/artmips.h).
+
+This is the whole FFI surface: plain pointers and sizes, no torch types.  The
+library is built in-tree by ``art_amd/csrc/build.sh`` (``__graft_entry__.build``)
+and there is no fallback: if it is missing, importing this module fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libartmips.so")
+
+F16, BF16, F32 = 0, 1, 2
+MAX_DEVICES = 16
+MAX_K = 2048
+SORT_MAX = 8192
+
+# every symbol include/artmips.h declares; tests check that the library exports each of them
+SYMBOLS = (
+    "artmips_create",
+    "artmips_destroy",
+    "artmips_begin",
+    "artmips_upload",
+    "artmips_upload_device",
+    "artmips_finalize",
+    "artmips_search",
+    "artmips_search_local",
+    "artmips_merge",
+    "artmips_info",
+    "artmips_last_error",
+    "artmips_version",
+)
+
+
+class ArtmipsInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_dev", ctypes.c_int32),
+        ("dim", ctypes.c_int32),
+        ("storage_dtype", ctypes.c_int32),
+        ("n_cu", ctypes.c_int32),
+        ("n_rows", ctypes.c_int64),
+        ("rows_per_shard", ctypes.c_int64 * MAX_DEVICES),
+        ("index_bytes", ctypes.c_int64),
+        ("workspace_bytes", ctypes.c_int64),
+        ("last_scan_ms", ctypes.c_float),
+        ("last_total_ms", ctypes.c_float),
+        ("last_scan_launches", ctypes.c_int32),
+        ("last_retries", ctypes.c_int32),
+        ("last_candidates", ctypes.c_int64),
+    ]
+
+
+class ArtmipsError(RuntimeError):
+    """A libartmips call returned a negative status; carries the C status string."""
+
+    def __init__(self, code, message):
+        super().__init__("artmips error %d: %s" % (code, message))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libartmips.so not found at %s. Build it with art_amd/csrc/build.sh "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the search path." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.artmips_create.argtypes = [ctypes.POINTER(ctypes.c_int), i32, i32, i32, ctypes.POINTER(vp)]
+    lib.artmips_create.restype = i32
+    lib.artmips_destroy.argtypes = [vp]
+    lib.artmips_destroy.restype = None
+    lib.artmips_begin.argtypes = [vp, i64]
+    lib.artmips_begin.restype = i32
+    lib.artmips_upload.argtypes = [vp, vp, vp, i64, i32]
+    lib.artmips_upload.restype = i32
+    lib.artmips_upload_device.argtypes = [vp, i32, vp, vp, i64, i64]
+    lib.artmips_upload_device.restype = i32
+    lib.artmips_finalize.argtypes = [vp]
+    lib.artmips_finalize.restype = i32
+    lib.artmips_search.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp]
+    lib.artmips_search.restype = i32
+    lib.artmips_search_local.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, vp]
+    lib.artmips_search_local.restype = i32
+    lib.artmips_merge.argtypes = [i32, vp, vp, i32, i64, i32, vp, i32, vp, vp]
+    lib.artmips_merge.restype = i32
+    lib.artmips_info.argtypes = [vp, ctypes.POINTER(ArtmipsInfo)]
+    lib.artmips_info.restype = i32
+    lib.artmips_last_error.argtypes = []
+    lib.artmips_last_error.restype = ctypes.c_char_p
+    lib.artmips_version.argtypes = []
+    lib.artmips_version.restype = i32
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise ArtmipsError(rc, lib.artmips_last_error().decode("utf-8", "replace"))

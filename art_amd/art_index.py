@@ -1,0 +1,267 @@
+"""Drop-in mirror of the reference's evidence store and brute-force MIPS index.
+
+Same names, arguments and error behaviour as
+``/root/reference/megatron/data/art_index.py`` (``detach`` :12,
+``OpenRetreivalDataStore`` :16-100, ``DistributedBruteForceIndex`` :200-304), so
+that ``megatron/model/art_model.py:12``, ``megatron/indexer.py:7`` and
+``tasks/.../evaluate.py:15`` work after a one-line import swap.
+The search itself runs in libartmips.so (hand-written gfx950 kernels behind the
+C ABI of include/artmips.h); there is no torch.matmul / torch.topk fallback.
+
+Differences from the reference, all deliberate:
+  * ties are broken by the LOWER passage id and scores are ranked in fp32 before
+    they are rounded to fp16 for the caller (the reference ranks fp16-rounded
+    scores with torch.topk's unspecified tie order, art_index.py:280-294);
+  * one process still drives every visible GPU (art_index.py:204), but only
+    Q*k (score, id) pairs per GPU move between devices instead of [Q, N/G] slabs;
+  * ``FaissMIPSIndex`` is not provided (faiss is out of scope).
+"""
+import os
+import pickle
+import shutil
+
+import numpy as np
+import torch
+
+
+def _megatron():
+    """(get_args, mpu) when this runs inside ART, else (None, None)."""
+    try:
+        from megatron import get_args, mpu  # type: ignore
+
+        return get_args, mpu
+    except Exception:
+        return None, None
+
+
+def _is_main_printer():
+    _, mpu = _megatron()
+    if mpu is None:
+        return True
+    try:
+        return mpu.is_unitialized() or mpu.get_data_parallel_rank() == 0
+    except Exception:
+        return True
+
+
+def detach(tensor):
+    """Same contract as art_index.py:12-13: a host numpy copy of a tensor."""
+    return tensor.detach().cpu().numpy()
+
+
+class OpenRetreivalDataStore(object):
+    """Evidence embeddings keyed by passage id, serialisable shard by shard.
+
+    Mirrors art_index.py:16-100.  ``embed_data`` is a ``dict {id -> np.float16[dim]}``
+    in insertion order; the on-disk artefact is one pickle ``{'embed_data': dict}``,
+    byte-compatible with the reference (tests/golden/fx_store_pickle).
+    """
+
+    def __init__(self, embedding_path=None, load_from_path=True, rank=None):
+        self.embed_data = dict()
+        if embedding_path is None:
+            get_args, _ = _megatron()
+            if get_args is None:
+                raise ValueError("embedding_path is required outside a megatron run")
+            args = get_args()
+            embedding_path = args.embedding_path
+            rank = args.rank
+        self.embedding_path = embedding_path
+        self.rank = rank
+
+        if load_from_path:
+            self.load_from_file()
+
+        self.temp_dir_name = os.path.splitext(self.embedding_path)[0] + '_tmp'
+
+    def state(self):
+        return {'embed_data': self.embed_data}
+
+    def clear(self):
+        """Drop the embeddings (the index owns them once they are on the GPUs)."""
+        self.embed_data = dict()
+
+    def load_from_file(self):
+        if _is_main_printer():
+            print("\n> Unpickling BlockData: ", self.embedding_path, flush=True)
+        with open(self.embedding_path, 'rb') as f:
+            state_dict = pickle.load(f)
+        if _is_main_printer():
+            print(">> Finished unpickling BlockData\n", flush=True)
+        self.embed_data = state_dict['embed_data']
+
+    def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
+        """Insert one batch; every row is cast to float16 (art_index.py:56-61).
+        Raises ValueError on a duplicate id unless allow_overwrite."""
+        for idx, embed in zip(row_id, block_embeds):
+            if not allow_overwrite and idx in self.embed_data:
+                raise ValueError("Unexpectedly tried to overwrite block data")
+            self.embed_data[idx] = np.float16(embed)
+
+    def save_shard(self):
+        """Write this rank's embeddings to <embedding_path stem>_tmp/<rank>.pkl."""
+        os.makedirs(self.temp_dir_name, exist_ok=True)
+        with open('{}/{}.pkl'.format(self.temp_dir_name, self.rank), 'wb') as writer:
+            pickle.dump(self.state(), writer)
+
+    def merge_shards_and_save(self):
+        """Fold every other rank's shard into this store (own shard first, the rest
+        in os.listdir order), assert there is no id overlap, write the merged pickle
+        and remove the temporary directory (art_index.py:72-100)."""
+        shard_names = os.listdir(self.temp_dir_name)
+        seen_own_shard = False
+
+        for fname in shard_names:
+            shard_rank = int(os.path.splitext(fname)[0])
+            if shard_rank == self.rank:
+                seen_own_shard = True
+                continue
+            with open(os.path.join(self.temp_dir_name, fname), 'rb') as f:
+                data = pickle.load(f)
+            before = len(self.embed_data)
+            incoming = len(data['embed_data'])
+            self.embed_data.update(data['embed_data'])
+            assert len(self.embed_data) == before + incoming
+
+        assert seen_own_shard
+
+        with open(self.embedding_path, 'wb') as final_file:
+            pickle.dump(self.state(), final_file)
+        shutil.rmtree(self.temp_dir_name, ignore_errors=True)
+
+        print("Finished merging {} shards for a total of {} embeds".format(
+            len(shard_names), len(self.embed_data)), flush=True)
+
+    # ---- not in the reference: bulk export used by the index upload ----------------------------
+    def iter_chunks(self, chunk_rows=65536):
+        """Yield (ids int64 [n], rows float16 [n, dim]) in dict insertion order."""
+        ids, rows = [], []
+        for idx, embed in self.embed_data.items():
+            ids.append(idx)
+            rows.append(embed)
+            if len(ids) == chunk_rows:
+                yield np.asarray(ids, dtype=np.int64), np.asarray(rows, dtype=np.float16)
+                ids, rows = [], []
+        if ids:
+            yield np.asarray(ids, dtype=np.int64), np.asarray(rows, dtype=np.float16)
+
+
+class _IdMap(object):
+    """Read-only stand-in for the reference's ``id_map`` dict (row position -> passage id,
+    art_index.py:257-259) that does not materialise 21M Python ints."""
+
+    def __init__(self, indices_arr):
+        self._arr = indices_arr
+
+    def __getitem__(self, pos):
+        return self._arr[pos]
+
+    def __len__(self):
+        return len(self._arr)
+
+    def __contains__(self, pos):
+        return 0 <= pos < len(self._arr)
+
+    def items(self):
+        return enumerate(self._arr)
+
+
+class DistributedBruteForceIndex(object):
+    """Exact MIPS index over every visible GPU; mirrors art_index.py:200-304."""
+
+    def __init__(self, embed_size, embed_data=None, devices=None, storage_dtype=torch.float16):
+        self.embed_size = embed_size
+        self.embed_data = embed_data
+        self.devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
+        self.ngpu = len(self.devices)
+        self.storage_dtype = storage_dtype
+        # fp16 is what the callers' broadcast buffers expect (art_model.py:358, evaluate.py:166)
+        self.score_dtype = torch.float16
+
+        self.evidence_embeds = None  # the MipsEngine that owns the device shards
+        self.indices_arr = None
+        self.id_map = dict()
+        self.num_rows = 0
+        self.chunksize = 0
+        self.last_chunksize = 0
+        self._set_mips_index()
+
+    def _set_mips_index(self):
+        if _is_main_printer():
+            print("\n> Building Brute Force MIPS index", flush=True)
+        if self.embed_data is not None:
+            self.add_embed_data(self.embed_data)
+
+    def reset_index(self):
+        """Drop the device shards and rebuild from a fresh store object."""
+        self._free()
+        if self.embed_data is not None:
+            embed_data_path = self.embed_data.embedding_path
+            del self.embed_data
+            self.embed_data = OpenRetreivalDataStore(embed_data_path)
+        self._set_mips_index()
+
+    def update_index(self):
+        """Drop the device shards, reload the store from disk and rebuild."""
+        self._free()
+        if self.embed_data is not None:
+            self.embed_data.load_from_file()
+        self._set_mips_index()
+
+    def _free(self):
+        if self.evidence_embeds is not None:
+            self.evidence_embeds.close()
+        self.evidence_embeds = None
+
+    def add_embed_data(self, all_embed_data):
+        """Move the store's rows to the GPUs (contiguous ceil-div row chunks, art_index.py:251-255)
+        and remember row position -> passage id.  Clears the store (art_index.py:262)."""
+        from .engine import MipsEngine
+
+        if self.ngpu < 1:
+            raise RuntimeError("DistributedBruteForceIndex needs at least one GPU")
+        n = len(all_embed_data.embed_data)
+        if n < 1:
+            raise ValueError("the store holds no embeddings")
+        engine = MipsEngine(self.embed_size, self.storage_dtype, self.devices)
+        engine.begin(n)
+        all_ids = np.empty(n, dtype=np.int64)
+        pos = 0
+        for ids, rows in all_embed_data.iter_chunks():
+            if rows.ndim != 2 or rows.shape[1] != self.embed_size:
+                raise ValueError("store rows have shape %s, index expects [*, %d]"
+                                 % (rows.shape, self.embed_size))
+            if ids.min() < -2 ** 31 or ids.max() > 2 ** 31 - 2:
+                raise ValueError("passage ids must fit in int32")
+            all_ids[pos:pos + len(ids)] = ids
+            pos += len(ids)
+            if self.storage_dtype == torch.float16:
+                engine.upload_host(rows, ids.astype(np.int32))
+            else:
+                engine.upload_host(torch.from_numpy(rows).to(self.storage_dtype), ids.astype(np.int32))
+        engine.finalize()
+        self._free()
+        self.evidence_embeds = engine
+        self.num_rows = n
+        self.chunksize = -(-n // self.ngpu)
+        self.last_chunksize = n - self.chunksize * (self.ngpu - 1)
+        self.indices_arr = all_ids
+        self.id_map = _IdMap(all_ids)
+
+        all_embed_data.clear()
+
+        if _is_main_printer():
+            print(">>> Finished adding block data to GPU index", flush=True)
+
+    def search_mips_index(self, query_embeds, top_k, reconstruct=True):
+        """Top-k passages by inner product.
+
+        Returns (distances [Q, k] float16, indices [Q, k] int32) on the query's device, rows
+        sorted by descending score, ties by lower passage id.  ``reconstruct`` is accepted and
+        ignored exactly as in the reference (art_index.py:267-270)."""
+        if self.evidence_embeds is None:
+            raise RuntimeError("MIPS index is empty: call add_embed_data first")
+        return self.evidence_embeds.search(query_embeds, top_k, score_dtype=self.score_dtype)
+
+
+__all__ = ["detach", "OpenRetreivalDataStore", "DistributedBruteForceIndex"]

@@ -1,0 +1,757 @@
+// artmips.hip — host side of libartmips.so (C ABI declared in include/artmips.h).
+//
+// Replaces the device orchestration of DistributedBruteForceIndex
+// (/root/reference/megatron/data/art_index.py:200-304): shard ownership, upload,
+// per-shard search pipeline, candidate exchange and merge.  No torch types; the
+// Python mirror of the reference classes lives in art_amd/art_index.py.
+#include "artmips_kernels.h"
+#include "../../include/artmips.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace artk;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(ARTMIPS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Generation {
+    void* rows = nullptr;   // [n_rows, dim] storage dtype
+    int32_t* ids = nullptr; // [n_rows]
+    int64_t n_rows = 0;
+    int64_t row0 = 0;       // global index of the shard's first row
+};
+
+struct Shard {
+    int dev = 0;
+    int n_cu = 0;
+    Generation live, next;
+    hipStream_t stream = nullptr;  // used when the caller's stream lives on another device
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;       // whole pipeline
+    std::vector<hipEvent_t> ev_scan;                   // pairs around each FILTER scan
+    // workspace
+    DevBuf qpad, thr, gmax, counts, lists, keys, status, qin, loc_scores, loc_ids;
+    int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints)
+};
+
+struct artmips {
+    int n_dev = 0;
+    int dim = 0;
+    int dtype = 0;
+    Shard sh[ARTMIPS_MAX_DEVICES];
+    bool building = false;
+    int64_t next_total = 0, next_chunk = 0, cursor = 0;
+    int64_t n_rows = 0, chunk = 0;
+    // staging for host uploads
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    // gather buffers on slot 0 for the multi-shard merge
+    DevBuf g_scores, g_ids, m_keys, m_status;
+    // stats
+    float last_scan_ms = 0, last_total_ms = 0;
+    int last_scan_launches = 0, last_retries = 0;
+    int64_t last_candidates = 0;
+    int cap_boost = 1;  // sticky multiplier learnt from overflow retries
+};
+
+static size_t elem_size(int dtype) { return dtype == ARTMIPS_F32 ? 4 : 2; }
+
+static int ensure(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return 0;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    // grow geometrically so that repeated small increases do not reallocate every call
+    size_t want = bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ARTMIPS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.bytes = want;
+    return 0;
+}
+
+static void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+static void free_generation(Generation& g) {
+    if (g.rows) (void)hipFree(g.rows);
+    if (g.ids) (void)hipFree(g.ids);
+    g = Generation();
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel launch tables
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DIM, int NSTAGE>
+static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
+    const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * 2;
+    static bool attr_done[ARTMIPS_MAX_DEVICES * 4] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (mode == MODE_FILTER) {
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER>;
+        if (dev < ARTMIPS_MAX_DEVICES * 4 && !attr_done[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+    } else {
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX>;
+        if (dev < ARTMIPS_MAX_DEVICES * 4 && !attr_done[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int launch_scan(int dtype, int dim, int mode, const ScanArgs& a, int grid, hipStream_t st) {
+    if (dtype == ARTMIPS_F16) {
+        if (dim == 768) return launch_scan_t<_Float16, 768, 6>(mode, a, grid, st);
+        if (dim == 1024) return launch_scan_t<_Float16, 1024, 4>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<_Float16, 128, 8>(mode, a, grid, st);
+    } else if (dtype == ARTMIPS_BF16) {
+        if (dim == 768) return launch_scan_t<__bf16, 768, 6>(mode, a, grid, st);
+        if (dim == 1024) return launch_scan_t<__bf16, 1024, 4>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<__bf16, 128, 8>(mode, a, grid, st);
+    }
+    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d storage_dtype=%d", dim, dtype);
+}
+
+static bool dim_supported(int dim) { return dim == 768 || dim == 1024 || dim == 128; }
+
+// ---------------------------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------------------------
+extern "C" int artmips_version(void) { return 1; }
+
+extern "C" const char* artmips_last_error(void) { return g_err; }
+
+extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int storage_dtype,
+                              artmips_t** out) {
+    if (!out) return fail(ARTMIPS_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_dev < 1 || n_dev > ARTMIPS_MAX_DEVICES)
+        return fail(ARTMIPS_ERR_ARG, "n_dev must be in [1, %d]", ARTMIPS_MAX_DEVICES);
+    if (storage_dtype != ARTMIPS_F16 && storage_dtype != ARTMIPS_BF16)
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "storage dtype %d: only f16 (0) and bf16 (1) rows",
+                    storage_dtype);
+    if (!dim_supported(dim))
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "dim %d: kernels are built for 128, 768 and 1024", dim);
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    for (int i = 0; i < n_dev; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= count)
+            return fail(ARTMIPS_ERR_ARG, "device id %d out of range (%d devices)", device_ids[i],
+                        count);
+    artmips* h = new (std::nothrow) artmips();
+    if (!h) return fail(ARTMIPS_ERR_NOMEM, "out of host memory");
+    h->n_dev = n_dev;
+    h->dim = dim;
+    h->dtype = storage_dtype;
+    for (int i = 0; i < n_dev; ++i) {
+        Shard& s = h->sh[i];
+        s.dev = device_ids[i];
+        DeviceGuard g(s.dev);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s.dev) != hipSuccess) {
+            artmips_destroy(h);
+            return fail(ARTMIPS_ERR_HIP, "hipGetDeviceProperties(%d) failed", s.dev);
+        }
+        s.n_cu = prop.multiProcessorCount;
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&s.ev_t0) != hipSuccess || hipEventCreate(&s.ev_t1) != hipSuccess ||
+            hipHostMalloc((void**)&s.status_host, 64, hipHostMallocDefault) != hipSuccess) {
+            artmips_destroy(h);
+            return fail(ARTMIPS_ERR_HIP, "stream/event creation failed on device %d", s.dev);
+        }
+        memset(s.status_host, 0, 64);
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void artmips_destroy(artmips_t* h) {
+    if (!h) return;
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        DeviceGuard g(s.dev);
+        (void)hipDeviceSynchronize();
+        free_generation(s.live);
+        free_generation(s.next);
+        DevBuf* bufs[] = {&s.qpad, &s.thr, &s.gmax, &s.counts, &s.lists, &s.keys,
+                          &s.status, &s.qin, &s.loc_scores, &s.loc_ids};
+        for (DevBuf* b : bufs) release(*b);
+        for (hipEvent_t e : s.ev_scan) (void)hipEventDestroy(e);
+        if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_t0) (void)hipEventDestroy(s.ev_t0);
+        if (s.ev_t1) (void)hipEventDestroy(s.ev_t1);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.status_host) (void)hipHostFree(s.status_host);
+    }
+    {
+        DeviceGuard g(h->sh[0].dev);
+        release(h->g_scores);
+        release(h->g_ids);
+        release(h->m_keys);
+        release(h->m_status);
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
+        }
+    }
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building an index generation
+// ---------------------------------------------------------------------------------------------
+extern "C" int artmips_begin(artmips_t* h, int64_t n_rows_total) {
+    if (!h) return fail(ARTMIPS_ERR_ARG, "handle is NULL");
+    if (n_rows_total < 1) return fail(ARTMIPS_ERR_ARG, "n_rows_total must be >= 1");
+    if (n_rows_total > 0x7fffffffLL * (int64_t)h->n_dev)
+        return fail(ARTMIPS_ERR_ARG, "more than 2^31-1 rows per shard");
+    // torch.chunk semantics (art_index.py:251-253): chunk = ceil(N/G); trailing shards may be
+    // short or empty
+    const int64_t chunk = (n_rows_total + h->n_dev - 1) / h->n_dev;
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        DeviceGuard g(s.dev);
+        free_generation(s.next);
+        const int64_t lo = std::min<int64_t>(chunk * i, n_rows_total);
+        const int64_t hi = std::min<int64_t>(chunk * (i + 1), n_rows_total);
+        s.next.row0 = lo;
+        s.next.n_rows = hi - lo;
+        if (s.next.n_rows > 0) {
+            const size_t rb = (size_t)s.next.n_rows * h->dim * elem_size(h->dtype);
+            hipError_t e = hipMalloc(&s.next.rows, rb);
+            if (e == hipSuccess) e = hipMalloc((void**)&s.next.ids, (size_t)s.next.n_rows * 4);
+            if (e != hipSuccess) {
+                free_generation(s.next);
+                return fail(ARTMIPS_ERR_NOMEM, "hipMalloc of shard %d (%zu bytes) failed: %s", i, rb,
+                            hipGetErrorString(e));
+            }
+        }
+    }
+    h->building = true;
+    h->next_total = n_rows_total;
+    h->next_chunk = chunk;
+    h->cursor = 0;
+    return 0;
+}
+
+extern "C" int artmips_upload(artmips_t* h, const void* host_rows, const int32_t* ids,
+                              int64_t n_rows, int flags) {
+    (void)flags;
+    if (!h || !host_rows || !ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_upload without artmips_begin");
+    if (n_rows < 0 || h->cursor + n_rows > h->next_total)
+        return fail(ARTMIPS_ERR_ARG, "upload of %lld rows at cursor %lld exceeds the %lld rows announced",
+                    (long long)n_rows, (long long)h->cursor, (long long)h->next_total);
+    const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
+    // pinned double buffer: sized for ~32 MiB of rows plus their ids
+    const int64_t rows_per_buf = std::max<int64_t>(1, (32ll << 20) / (int64_t)row_bytes);
+    const size_t need = (size_t)rows_per_buf * (row_bytes + 4);
+    {
+        DeviceGuard g(h->sh[0].dev);
+        if (h->pin_bytes < need) {
+            for (int i = 0; i < 2; ++i) {
+                if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+                h->pin[i] = nullptr;
+                HIP_TRY(hipHostMalloc(&h->pin[i], need, hipHostMallocDefault));
+                if (!h->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+            }
+            h->pin_bytes = need;
+        }
+    }
+    int which = 0;
+    bool used[2] = {false, false};
+    int64_t done = 0;
+    while (done < n_rows) {
+        const int64_t gpos = h->cursor + done;
+        const int slot = (int)(gpos / h->next_chunk);
+        Shard& s = h->sh[slot];
+        const int64_t in_shard = gpos - s.next.row0;
+        const int64_t n = std::min<int64_t>(std::min<int64_t>(rows_per_buf, n_rows - done),
+                                            s.next.n_rows - in_shard);
+        if (used[which]) HIP_TRY(hipEventSynchronize(h->pin_ev[which]));
+        char* stage = (char*)h->pin[which];
+        memcpy(stage, (const char*)host_rows + (size_t)done * row_bytes, (size_t)n * row_bytes);
+        memcpy(stage + (size_t)rows_per_buf * row_bytes, ids + done, (size_t)n * 4);
+        {
+            DeviceGuard g(s.dev);
+            HIP_TRY(hipMemcpyAsync((char*)s.next.rows + (size_t)in_shard * row_bytes, stage,
+                                   (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(hipMemcpyAsync(s.next.ids + in_shard, stage + (size_t)rows_per_buf * row_bytes,
+                                   (size_t)n * 4, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(hipEventRecord(h->pin_ev[which], s.stream));
+        }
+        used[which] = true;
+        which ^= 1;
+        done += n;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (used[i]) HIP_TRY(hipEventSynchronize(h->pin_ev[i]));
+    h->cursor += n_rows;
+    return 0;
+}
+
+extern "C" int artmips_upload_device(artmips_t* h, int slot, const void* dev_rows,
+                                     const int32_t* dev_ids, int64_t n, int64_t row_offset) {
+    if (!h || !dev_rows || !dev_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_upload_device without artmips_begin");
+    if (slot < 0 || slot >= h->n_dev) return fail(ARTMIPS_ERR_ARG, "slot %d out of range", slot);
+    Shard& s = h->sh[slot];
+    if (n < 0 || row_offset < 0 || row_offset + n > s.next.n_rows)
+        return fail(ARTMIPS_ERR_ARG, "rows [%lld, %lld) outside shard %d of %lld rows",
+                    (long long)row_offset, (long long)(row_offset + n), slot, (long long)s.next.n_rows);
+    if (n == 0) return 0;
+    DeviceGuard g(s.dev);
+    const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
+    // the source may have been produced on another stream (torch's): order against everything
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyAsync((char*)s.next.rows + (size_t)row_offset * row_bytes, dev_rows,
+                           (size_t)n * row_bytes, hipMemcpyDeviceToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.next.ids + row_offset, dev_ids, (size_t)n * 4, hipMemcpyDeviceToDevice,
+                           s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+extern "C" int artmips_finalize(artmips_t* h) {
+    if (!h) return fail(ARTMIPS_ERR_ARG, "handle is NULL");
+    if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_finalize without artmips_begin");
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        DeviceGuard g(s.dev);
+        HIP_TRY(hipDeviceSynchronize());  // uploads landed, no search is using the old rows
+        free_generation(s.live);
+        s.live = s.next;
+        s.next = Generation();
+    }
+    h->n_rows = h->next_total;
+    h->chunk = h->next_chunk;
+    h->building = false;
+    h->cap_boost = 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-shard search pipeline
+// ---------------------------------------------------------------------------------------------
+struct Plan {
+    bool pass0;
+    int grid0;            // blocks of the GROUPMAX scan
+    long long n_sample;   // sample tiles
+    long long sample_stride;
+    int grid;             // blocks of the FILTER scan
+    int cap;              // entries per candidate list
+    long long n_tiles;
+};
+
+static int round_up_pow2(long long x) {
+    long long p = 1;
+    while (p < x) p <<= 1;
+    return (int)std::min<long long>(p, 1ll << 30);
+}
+
+static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
+    Plan p;
+    p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu));
+    const long long tiles_per_block = (p.n_tiles + p.grid - 1) / p.grid;
+    const long long cap_max = tiles_per_block * 4;  // rows one lane can ever see
+    // pass 0: groups = lanes of the sample scan that share a query = grid0 * 4.  Want >= 8k groups
+    // (so that the k-th largest group maximum is close to the k-th best of the sample) and a sample
+    // of about 1/128 of the rows, but never more than 1/4 of them.
+    long long groups = std::max<long long>(1024, 8ll * k);
+    long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
+    long long sample = std::max<long long>(grid0, p.n_tiles / 128);
+    p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
+    if (p.pass0) {
+        const long long t0 = std::max<long long>(1, sample / grid0);
+        p.grid0 = (int)grid0;
+        p.n_sample = grid0 * t0;
+        p.sample_stride = p.n_tiles / p.n_sample;
+        // expected survivors per query: k * n_tiles / n_sample (loose by the group approximation)
+        const double expect = (double)k * (double)p.n_tiles / (double)p.n_sample;
+        const double per_list = expect / ((double)p.grid * 4.0);
+        long long cap = round_up_pow2((long long)std::ceil(per_list * 8.0) + 16);
+        cap *= cap_boost;
+        p.cap = (int)std::min<long long>(cap, cap_max);
+    } else {
+        p.grid0 = 0;
+        p.n_sample = 0;
+        p.sample_stride = 1;
+        p.cap = (int)cap_max;  // threshold is -inf: every row is a candidate
+    }
+    if (p.cap < 1) p.cap = 1;
+    return p;
+}
+
+template <typename T>
+static void launch_pack(const void* q, int q_dtype, int q_count, int dim, void* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(64), dim3(256), 0, st, q, q_dtype, q_count, dim,
+                       (T*)out);
+}
+
+// Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
+static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile, int q_dtype,
+                        int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
+                        long long out_row0, hipStream_t st, int tile_index) {
+    const Generation& gen = s.live;
+    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, h->dim, s.qpad.p, st);
+    else launch_pack<__bf16>(q_tile, q_dtype, q_count, h->dim, s.qpad.p, st);
+    HIP_TRY(hipGetLastError());
+
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = gen.rows;
+    a.n_rows = gen.n_rows;
+    a.qpad = s.qpad.p;
+    a.q_count = q_count;
+    a.thr = (const float*)s.thr.p;
+    a.lists = (int2*)s.lists.p;
+    a.counts = (int*)s.counts.p;
+    a.cap = p.cap;
+    a.gmax = (float*)s.gmax.p;
+
+    if (p.pass0) {
+        a.n_work = p.n_sample;
+        a.tile_stride = p.sample_stride;
+        int rc = launch_scan(h->dtype, h->dim, MODE_GROUPMAX, a, p.grid0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kth_kernel, dim3(QTILE), dim3(SEL_THREADS), (size_t)p.grid0 * 4 * 4, st,
+                           (const float*)s.gmax.p, p.grid0, k, q_count, (float*)s.thr.p);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(64), 0, st, (float*)s.thr.p, q_count);
+        HIP_TRY(hipGetLastError());
+    }
+
+    a.n_work = p.n_tiles;
+    a.tile_stride = 1;
+    while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s.ev_scan.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
+    int rc = launch_scan(h->dtype, h->dim, MODE_FILTER, a, p.grid, st);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
+
+    SelectArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.lists = (const int2*)s.lists.p;
+    sa.counts = (const int*)s.counts.p;
+    sa.cap = p.cap;
+    sa.scan_grid = p.grid;
+    sa.ids = gen.ids;
+    sa.keys_ws = (u64*)s.keys.p;
+    sa.keys_stride = (long long)(s.keys.bytes / 8 / QTILE);
+    sa.k = k;
+    sa.out_scores = out_scores;
+    sa.score_dtype = score_dtype;
+    sa.out_ids = out_ids;
+    sa.out_row0 = out_row0;
+    sa.status = (int*)s.status.p;
+    sa.cand_total = (unsigned long long*)((int*)s.status.p + 2);
+    hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(SEL_THREADS), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Full local search of one shard for n_q queries, enqueued on st; outputs [n_q, k].
+// Returns after the stream has been synchronised and overflow retries (if any) are done.
+static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                        void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
+                        bool record_stats) {
+    Shard& s = h->sh[slot];
+    const Generation& gen = s.live;
+    DeviceGuard g(s.dev);
+    if (gen.n_rows == 0) {
+        return fail(ARTMIPS_ERR_STATE, "shard %d is empty", slot);
+    }
+    const size_t q_row_bytes = (size_t)h->dim * elem_size(q_dtype);
+    int retries = 0;
+    for (;;) {
+        Plan p = make_plan(s, gen.n_rows, k, h->cap_boost);
+        // workspace
+        int rc = 0;
+        if ((rc = ensure(s.qpad, (size_t)QTILE * h->dim * 2))) return rc;
+        if ((rc = ensure(s.thr, QTILE * 4))) return rc;
+        if ((rc = ensure(s.status, 64))) return rc;
+        if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * SCAN_THREADS * 4))) return rc;
+        if ((rc = ensure(s.counts, (size_t)p.grid * SCAN_THREADS * 4))) return rc;
+        const size_t list_entries = (size_t)p.grid * SCAN_THREADS * (size_t)p.cap;
+        if ((rc = ensure(s.lists, list_entries * 8))) return rc;
+        // global key scratch: worst case every list of a query is full
+        const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
+        if (keys_per_q > (size_t)SORT_MAX) {
+            if ((rc = ensure(s.keys, keys_per_q * 8 * QTILE))) return rc;
+        }
+        HIP_TRY(hipMemsetAsync(s.status.p, 0, 64, st));
+        if (record_stats) HIP_TRY(hipEventRecord(s.ev_t0, st));
+        int n_tiles_q = 0;
+        for (int64_t q0 = 0; q0 < n_q; q0 += QTILE, ++n_tiles_q) {
+            const int qc = (int)std::min<int64_t>(QTILE, n_q - q0);
+            rc = enqueue_tile(h, s, p, (const char*)q_dev + (size_t)q0 * q_row_bytes, q_dtype, qc, k,
+                              out_scores, score_dtype, out_ids, q0, st, n_tiles_q);
+            if (rc) return rc;
+        }
+        if (record_stats) HIP_TRY(hipEventRecord(s.ev_t1, st));
+        HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int status = s.status_host[0];
+        if (status & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
+        if (status & 1) {
+            // a candidate list overflowed: the result may have lost a top-k member.  Enlarge the
+            // lists and rescan; at cap == rows-per-lane overflow is impossible, so this ends.
+            ++retries;
+            if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
+            h->cap_boost *= 8;
+            continue;
+        }
+        if (record_stats) {
+            float ms = 0, total = 0;
+            for (int t = 0; t < n_tiles_q; ++t) {
+                float x = 0;
+                HIP_TRY(hipEventElapsedTime(&x, s.ev_scan[2 * t], s.ev_scan[2 * t + 1]));
+                ms += x;
+            }
+            HIP_TRY(hipEventElapsedTime(&total, s.ev_t0, s.ev_t1));
+            h->last_scan_ms = ms;
+            h->last_total_ms = total;
+            h->last_scan_launches = n_tiles_q;
+            h->last_retries = retries;
+            unsigned long long c = 0;
+            memcpy(&c, s.status_host + 2, 8);
+            h->last_candidates = (int64_t)c;
+        }
+        return 0;
+    }
+}
+
+static int check_search_args(artmips* h, const void* q, int q_dtype, int64_t n_q, int k,
+                             const void* out_scores, const void* out_ids) {
+    if (!h || !q || !out_scores || !out_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (h->n_rows < 1) return fail(ARTMIPS_ERR_STATE, "search on an empty index (no artmips_finalize yet)");
+    if (q_dtype < 0 || q_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad query dtype %d", q_dtype);
+    if (n_q < 1) return fail(ARTMIPS_ERR_ARG, "n_q must be >= 1");
+    if (k < 1) return fail(ARTMIPS_ERR_ARG, "top_k must be >= 1 (got %d)", k);
+    return 0;
+}
+
+extern "C" int artmips_search_local(artmips_t* h, int slot, const void* q_dev, int q_dtype,
+                                    int64_t n_q, int k, float* out_scores, int32_t* out_ids,
+                                    void* stream) {
+    int rc = check_search_args(h, q_dev, q_dtype, n_q, k, out_scores, out_ids);
+    if (rc) return rc;
+    if (slot < 0 || slot >= h->n_dev) return fail(ARTMIPS_ERR_ARG, "slot %d out of range", slot);
+    const int64_t n_local = h->sh[slot].live.n_rows;
+    if (k > ARTMIPS_MAX_K && n_local > SORT_MAX)
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k, ARTMIPS_MAX_K,
+                    (long long)n_local);
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    return search_shard(h, slot, q_dev, q_dtype, n_q, k, out_scores, ARTMIPS_F32, out_ids,
+                        (hipStream_t)stream, true);
+}
+
+static int run_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
+                     int k, void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
+                     DevBuf* keys, DevBuf* status_buf) {
+    DeviceGuard g(device);
+    MergeArgs m;
+    memset(&m, 0, sizeof(m));
+    m.scores = scores;
+    m.ids = ids;
+    m.n_lists = n_lists;
+    m.n_q = n_q;
+    m.k = k;
+    m.out_scores = out_scores;
+    m.score_dtype = score_dtype;
+    m.out_ids = out_ids;
+    const long long total = (long long)n_lists * k;
+    DevBuf local_keys, local_status;
+    DevBuf* kb = keys ? keys : &local_keys;
+    DevBuf* sb = status_buf ? status_buf : &local_status;
+    int rc = 0;
+    if ((rc = ensure(*sb, 64))) return rc;
+    if (total > SORT_MAX) {
+        if ((rc = ensure(*kb, (size_t)total * 8 * (size_t)n_q))) { release(local_status); return rc; }
+        m.keys_ws = (u64*)kb->p;
+        m.keys_stride = total;
+    }
+    m.status = (int*)sb->p;
+    hipError_t e = hipMemsetAsync(sb->p, 0, 64, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n_q), dim3(SEL_THREADS), 0, st, m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    release(local_keys);
+    release(local_status);
+    if (e != hipSuccess) return fail(ARTMIPS_ERR_HIP, "merge failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int artmips_merge(int device, const float* scores, const int32_t* ids, int n_lists,
+                             int64_t n_q, int k, void* out_scores, int score_dtype,
+                             int32_t* out_ids, void* stream) {
+    if (!scores || !ids || !out_scores || !out_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (n_lists < 1 || n_q < 1 || k < 1) return fail(ARTMIPS_ERR_ARG, "n_lists, n_q and k must be >= 1");
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
+    return run_merge(device, scores, ids, n_lists, n_q, k, out_scores, score_dtype, out_ids,
+                     (hipStream_t)stream, nullptr, nullptr);
+}
+
+extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                              void* out_scores, int score_dtype, int32_t* out_ids, void* stream) {
+    int rc = check_search_args(h, q_dev, q_dtype, n_q, k, out_scores, out_ids);
+    if (rc) return rc;
+    if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
+    if ((int64_t)k > h->n_rows)
+        return fail(ARTMIPS_ERR_ARG, "top_k %d exceeds the %lld rows of the index", k, (long long)h->n_rows);
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    int active = 0;
+    for (int i = 0; i < h->n_dev; ++i) {
+        if (h->sh[i].live.n_rows > 0) ++active;
+        if (k > ARTMIPS_MAX_K && h->sh[i].live.n_rows > SORT_MAX)
+            return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k,
+                        ARTMIPS_MAX_K, (long long)h->sh[i].live.n_rows);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (active == 1 && h->sh[0].live.n_rows > 0) {
+        return search_shard(h, 0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, true);
+    }
+    // several shards driven by this one process (the reference's model, art_index.py:273-291):
+    // replicate the queries, search every shard on its own stream, bring the (score, id) lists
+    // to slot 0 and merge there.  Only Q*k*8 bytes per shard move between devices.
+    Shard& s0 = h->sh[0];
+    const size_t q_bytes = (size_t)n_q * h->dim * elem_size(q_dtype);
+    const size_t list_elems = (size_t)n_q * k;
+    {
+        DeviceGuard g(s0.dev);
+        if ((rc = ensure(h->g_scores, list_elems * 4 * active))) return rc;
+        if ((rc = ensure(h->g_ids, list_elems * 4 * active))) return rc;
+        HIP_TRY(hipEventRecord(s0.ev_ready, st));
+    }
+    int li = 0;
+    std::vector<int> used;
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        if (s.live.n_rows == 0) continue;
+        DeviceGuard g(s.dev);
+        if ((rc = ensure(s.qin, q_bytes))) return rc;
+        if ((rc = ensure(s.loc_scores, list_elems * 4))) return rc;
+        if ((rc = ensure(s.loc_ids, list_elems * 4))) return rc;
+        HIP_TRY(hipStreamWaitEvent(s.stream, s0.ev_ready, 0));
+        HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
+        used.push_back(i);
+    }
+    // the shard pipelines synchronise their own stream (status word), so they run one after the
+    // other from this thread; the kernels of different devices still overlap because every
+    // pipeline is fully enqueued before its synchronise and device queues are independent.
+    for (int i : used) {
+        Shard& s = h->sh[i];
+        rc = search_shard(h, i, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
+                          (int32_t*)s.loc_ids.p, s.stream, i == used[0]);
+        if (rc) return rc;
+        DeviceGuard g(s.dev);
+        HIP_TRY(hipMemcpyPeerAsync((char*)h->g_scores.p + (size_t)li * list_elems * 4, s0.dev,
+                                   s.loc_scores.p, s.dev, list_elems * 4, s.stream));
+        HIP_TRY(hipMemcpyPeerAsync((char*)h->g_ids.p + (size_t)li * list_elems * 4, s0.dev,
+                                   s.loc_ids.p, s.dev, list_elems * 4, s.stream));
+        HIP_TRY(hipEventRecord(s.ev_done, s.stream));
+        ++li;
+    }
+    {
+        DeviceGuard g(s0.dev);
+        for (int i : used) HIP_TRY(hipStreamWaitEvent(st, h->sh[i].ev_done, 0));
+    }
+    return run_merge(s0.dev, (const float*)h->g_scores.p, (const int32_t*)h->g_ids.p, active, n_q, k,
+                     out_scores, score_dtype, out_ids, st, &h->m_keys, &h->m_status);
+}
+
+extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
+    if (!h || !out) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->n_dev = h->n_dev;
+    out->dim = h->dim;
+    out->storage_dtype = h->dtype;
+    out->n_cu = h->sh[0].n_cu;
+    out->n_rows = h->n_rows;
+    size_t ws = h->g_scores.bytes + h->g_ids.bytes + h->m_keys.bytes + h->m_status.bytes;
+    for (int i = 0; i < h->n_dev; ++i) {
+        const Shard& s = h->sh[i];
+        out->rows_per_shard[i] = s.live.n_rows;
+        out->index_bytes += (int64_t)s.live.n_rows * h->dim * (int64_t)elem_size(h->dtype);
+        ws += s.qpad.bytes + s.thr.bytes + s.gmax.bytes + s.counts.bytes + s.lists.bytes +
+              s.keys.bytes + s.status.bytes + s.qin.bytes + s.loc_scores.bytes + s.loc_ids.bytes;
+    }
+    out->workspace_bytes = (int64_t)ws;
+    out->last_scan_ms = h->last_scan_ms;
+    out->last_total_ms = h->last_total_ms;
+    out->last_scan_launches = h->last_scan_launches;
+    out->last_retries = h->last_retries;
+    out->last_candidates = h->last_candidates;
+    return 0;
+}

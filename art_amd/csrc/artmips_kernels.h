@@ -1,0 +1,570 @@
+// artmips_kernels.h — gfx950 (MI355X, CDNA4) device code for exact MIPS top-k.
+//
+// Replaces the GPU side of DistributedBruteForceIndex.search_mips_index
+// (/root/reference/megatron/data/art_index.py:278-294): instead of a full
+// [Q, N] score matrix followed by torch.topk, the evidence rows are streamed
+// ONCE from HBM through an LDS ring (LDS-DMA, 1 KiB per wave-instruction), scored
+// on MFMA with fp32 accumulation, and filtered in registers against a per-query
+// lower bound of the k-th best score.  Only the survivors (a few thousand per
+// query out of 21M rows) are written out and sorted.
+//
+// Kernels
+//   pack_queries_kernel   queries (f16/bf16/f32) -> padded [64, DIM] tile in the storage dtype
+//   scan_kernel<GROUPMAX> pass 0: per-lane running max over a strided row sample
+//   kth_kernel            pass 0: tau[q] = k-th largest group maximum  (a valid lower bound)
+//   scan_kernel<FILTER>   the hot kernel: stream all rows, keep (score,row) with score >= tau[q]
+//   select_kernel         per query: gather candidates, exact top-k by (score desc, id asc)
+//   merge_kernel          per query: top-k of the union of per-shard top-k lists
+//
+// Layout facts the kernels rely on (checked on the host before every launch):
+//   rows: [n_rows, DIM] row-major, 16-byte aligned, DIM % 128 == 0
+//   a "tile" is 16 consecutive rows; a "piece" is 8 rows x 128 B = one LDS-DMA wave-instruction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace artk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int QTILE = 64;        // queries per scan pass (4 waves x 16 MFMA columns)
+constexpr int SCAN_THREADS = 256;
+constexpr int TILE_ROWS = 16;    // rows per LDS stage (one 16x16x32 MFMA row block)
+constexpr int SORT_MAX = 8192;   // 64-bit keys sorted in LDS by select/merge (64 KiB)
+constexpr int SEL_THREADS = 1024;
+
+enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// element helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<_Float16> {
+    typedef half8 V;
+    static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+};
+template <> struct Elem<__bf16> {
+    typedef bf16x8 V;
+    static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
+};
+
+// Orderable 32-bit image of a float: larger float <=> larger unsigned. -0 is folded into +0 so
+// that the two compare equal in the key as they do as floats.
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    if (f == 0.0f) f = 0.0f;
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// 64-bit selection key: larger key == better candidate (higher score, then LOWER passage id).
+__device__ __forceinline__ u64 make_key(float score, int32_t id) {
+    uint32_t lo = ~(((uint32_t)id) ^ 0x80000000u);
+    return ((u64)f2ord(score) << 32) | (u64)lo;
+}
+__device__ __forceinline__ float key_score(u64 key) { return ord2f((uint32_t)(key >> 32)); }
+__device__ __forceinline__ int32_t key_id(u64 key) {
+    return (int32_t)((~(uint32_t)key) ^ 0x80000000u);
+}
+
+__device__ __forceinline__ void store_score(void* out, int dtype, int64_t idx, float s) {
+    if (dtype == 0) ((_Float16*)out)[idx] = (_Float16)s;
+    else if (dtype == 1) ((__bf16*)out)[idx] = (__bf16)s;
+    else ((float*)out)[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack_queries_kernel: [q_count, dim] (f16 / bf16 / f32) -> [64, dim] storage dtype, zero padded.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_queries_kernel(const void* __restrict__ q, int q_dtype, int q_count, int dim,
+                                    T* __restrict__ out) {
+    const int total = QTILE * dim;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int row = i / dim;
+        float v = 0.0f;
+        if (row < q_count) {
+            if (q_dtype == 0) v = (float)((const _Float16*)q)[i];
+            else if (q_dtype == 1) v = (float)((const __bf16*)q)[i];
+            else v = ((const float*)q)[i];
+        }
+        out[i] = Elem<T>::from_float(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan_kernel
+// ---------------------------------------------------------------------------------------------
+struct ScanArgs {
+    const void* rows;     // [n_rows, DIM] storage dtype
+    long long n_rows;
+    long long n_work;     // tiles (or sample tiles) to visit in this launch
+    long long tile_stride;// actual tile = work index * tile_stride  (1 for the full scan)
+    const void* qpad;     // [64, DIM] storage dtype
+    int q_count;          // real queries in the tile (<= 64)
+    const float* thr;     // [64] FILTER: keep score >= thr[q]
+    int2* lists;          // FILTER: [grid*256][cap] (score bits, local row)
+    int* counts;          // FILTER: [grid*256] candidates seen by each lane (may exceed cap)
+    int cap;
+    float* gmax;          // GROUPMAX: [grid*256] running max of each lane
+};
+
+// kappa: which 16-byte chunk (0..7) of a 128-byte column block lane group g = lane>>4 multiplies
+// in MFMA k-step half e.  Any bijection (g,e)->0..7 is numerically valid as long as the row
+// operand and the query operand agree (the dot product is a sum over k in any order); this one
+// makes the ds_read_b128 of the row operand bank-conflict free (DESIGN.md §LDS image).
+__device__ __forceinline__ int kappa(int g, int e) { return 4 * (g & 1) + 2 * e + (g >> 1); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int DIM, int NSTAGE, int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
+    typedef typename Elem<T>::V V;
+    constexpr int J = DIM / 64;            // 128-byte column blocks per row
+    constexpr int PIECES = 2 * J;          // 1-KiB pieces per 16-row stage
+    constexpr int PPW = PIECES / 4;        // pieces each of the 4 waves issues per stage
+    constexpr int STAGE_BYTES = TILE_ROWS * DIM * 2;
+    static_assert(DIM % 128 == 0, "DIM must be a multiple of 128");
+    static_assert((NSTAGE - 2) * PPW <= 63, "vmcnt field is 6 bits");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15;  // MFMA row (row operand) / column (query operand) of this lane
+    const int g = lane >> 4;  // MFMA k-group of this lane
+    const bool wave_active = (w * 16) < a.q_count;
+
+    const T* __restrict__ rows = (const T*)a.rows;
+    const long long n_rows = a.n_rows;
+    const long long last_row = n_rows - 1;
+
+    // ---- query operand: 2*J fragments of 8 elements, resident in registers for the whole launch
+    V bq[2 * J];
+    {
+        const T* qrow = (const T*)a.qpad + (size_t)(w * 16 + r) * DIM;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                bq[2 * j + e] = *(const V*)(qrow + (8 * j + kappa(g, e)) * 8);
+            }
+        }
+    }
+    float thr = 0.0f;
+    if (MODE == MODE_FILTER) thr = a.thr[w * 16 + r];
+    // drain the ordinary loads before any LDS-DMA is in flight, so that hipcc never has a reason to
+    // put a vmcnt(0) inside the streaming loop
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < 2 * J; ++i) asm volatile("" : "+v"(bq[i]));
+    asm volatile("" : "+v"(thr));
+
+    // ---- per-lane constants of the LDS image
+    // DMA side: lane i of piece (j, half) fetches row 8*half + (i>>3), chunk 8j + ((i&7) ^ ((i>>3)>>1))
+    const int rho = lane >> 3;
+    const int xch = (lane & 7) ^ (rho >> 1);
+    // MFMA side: lane (r,g) at k-step (j,e) reads slot (r&7)*8 + (kappa(g,e) ^ ((r&7)>>1)) of piece (j, r>>3)
+    const int rd_off0 = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 0) ^ ((r & 7) >> 1))) * 16;
+    const int rd_off1 = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 1) ^ ((r & 7) >> 1))) * 16;
+
+    const long long n_work = a.n_work;
+    const long long stride = a.tile_stride;
+    const long long b = blockIdx.x;
+    const long long grid = gridDim.x;
+    const long long n_it = (b < n_work) ? (n_work - b + grid - 1) / grid : 0;
+    const long long last_work = n_work - 1;
+
+    auto issue_stage = [&](long long it, int slot) {
+        long long wk = b + it * grid;
+        if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
+        const long long row0 = wk * stride * TILE_ROWS;
+        char* slot_base = smem + slot * STAGE_BYTES;
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int p = w * PPW + pp;
+            const int j = p >> 1, half = p & 1;
+            long long row = row0 + 8 * half + rho;
+            if (row > last_row) row = last_row;
+            const T* src = rows + row * DIM + j * 64 + xch * 8;
+            glds16(src, slot_base + p * 1024);
+        }
+    };
+
+    int cnt = 0;
+    float gm = -INFINITY;
+    int2* my_list = nullptr;
+    if (MODE == MODE_FILTER) my_list = a.lists + ((size_t)b * SCAN_THREADS + tid) * (size_t)a.cap;
+
+    if (n_it > 0) {
+        // prologue: NSTAGE-1 stages in flight
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s) issue_stage(s, s);
+
+        int slot = 0;
+        int fill_slot = NSTAGE - 1;
+        for (long long it = 0; it < n_it; ++it) {
+            // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
+            wait_vmcnt<(NSTAGE - 2) * PPW>();
+            asm volatile("s_barrier" ::: "memory");
+            // every wave has finished reading the slot consumed in the previous iteration: refill it
+            issue_stage(it + NSTAGE - 1, fill_slot);
+            fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
+
+            if (wave_active) {
+                const char* sb = smem + slot * STAGE_BYTES;
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                // all row fragments of the stage are requested before the first MFMA, so the LDS
+                // latency is paid once per stage and not once per k-step
+                V af[2 * J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    af[2 * j] = *(const V*)(sb + j * 2048 + rd_off0);
+                    af[2 * j + 1] = *(const V*)(sb + j * 2048 + rd_off1);
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * J; ++j) acc = Elem<T>::mfma(af[j], bq[j], acc);
+                // pin the order in the emitted code: 2J ds_read_b128, then 2J MFMAs behind counted
+                // lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA to save VGPRs)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * J, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * J, 0);
+                // acc[i] = score(row = tile*16 + g*4 + i, query = w*16 + r)
+                const long long row_base = (b + it * grid) * stride * TILE_ROWS + g * 4;
+                if (MODE == MODE_FILTER) {
+                    const float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                    if (__builtin_amdgcn_ballot_w64(m >= thr) != 0ull) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const long long row = row_base + i;
+                            if (acc[i] >= thr && row < n_rows) {
+                                if (cnt < a.cap)
+                                    my_list[cnt] = make_int2(__float_as_int(acc[i]), (int)row);
+                                ++cnt;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long row = row_base + i;
+                        if (row < n_rows) gm = fmaxf(gm, acc[i]);
+                    }
+                }
+            }
+            slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+        }
+        // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
+        wait_vmcnt<0>();
+    }
+    if (MODE == MODE_FILTER) a.counts[(size_t)b * SCAN_THREADS + tid] = cnt;
+    else a.gmax[(size_t)b * SCAN_THREADS + tid] = gm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kth_kernel (pass 0): tau[q] = k-th largest of the per-lane maxima that belong to query q.
+// Each maximum is the score of a distinct row, so k of them >= tau proves that the k-th best
+// score over the whole shard is >= tau: dropping every score < tau loses no top-k member.
+// One block per query slot (64 blocks); dynamic LDS = n_groups * 4 bytes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
+                                                          int scan_grid, int k, int q_count,
+                                                          float* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* vals = (uint32_t*)smem;
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_kk;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int G = scan_grid * 4;
+    if (q >= q_count) {
+        if (tid == 0) thr[q] = INFINITY;  // padded query: never keep anything
+        return;
+    }
+    if (G < k) {
+        if (tid == 0) thr[q] = -INFINITY;
+        return;
+    }
+    for (int i = tid; i < G; i += SEL_THREADS) {
+        const int bb = i >> 2, gg = i & 3;
+        vals[i] = f2ord(gmax[(size_t)bb * SCAN_THREADS + (q >> 4) * 64 + gg * 16 + (q & 15)]);
+    }
+    if (tid == 0) { s_prefix = 0; s_kk = k; }
+    __syncthreads();
+    for (int byte = 3; byte >= 0; --byte) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t mask = (byte == 3) ? 0u : (0xffffffffu << ((byte + 1) * 8));
+        const uint32_t prefix = s_prefix;
+        for (int i = tid; i < G; i += SEL_THREADS) {
+            const uint32_t v = vals[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> (byte * 8)) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int kk = s_kk, cum = 0, sel = 0;
+            for (int bin = 255; bin >= 0; --bin) {
+                const int c = hist[bin];
+                if (cum + c >= kk) { sel = bin; kk -= cum; break; }
+                cum += c;
+            }
+            s_kk = kk;
+            s_prefix = prefix | ((uint32_t)sel << (byte * 8));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) thr[q] = ord2f(s_prefix);
+}
+
+// thresholds when pass 0 is skipped (small shards): keep everything for real queries
+__global__ void fill_thr_kernel(float* thr, int q_count) {
+    const int q = threadIdx.x;
+    if (q < QTILE) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact top-k of a set of distinct 64-bit keys
+// ---------------------------------------------------------------------------------------------
+// bitonic sort, descending, of P (power of two, <= SORT_MAX) keys in LDS
+__device__ void bitonic_sort_desc(u64* s, int P) {
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += blockDim.x) {
+                const int pos = 2 * i - (i & (stride - 1));
+                const int par = pos + stride;
+                const bool desc = ((pos & size) == 0);
+                const u64 x = s[pos], y = s[par];
+                if ((x < y) == desc) { s[pos] = y; s[par] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+struct TopkOut {
+    void* scores;     // [*, k] score_dtype
+    int score_dtype;
+    int32_t* ids;     // [*, k]
+    long long row;    // output row (query index)
+    int k;
+};
+
+// Keys are either already in LDS (M <= SORT_MAX, unsorted, in skeys[0..M)) or in global memory
+// gkeys[0..M).  Writes the k best in order; slots beyond M get (-inf, INT32_MAX).
+// hist: 256 ints of LDS, sctl: 4 x u64 of LDS.
+__device__ void topk_finish(u64* skeys, const u64* gkeys, int M, bool in_lds, int* hist, u64* sctl,
+                            const TopkOut& o) {
+    const int tid = threadIdx.x;
+    const int k = o.k;
+    int n_sorted;  // number of real keys in skeys after sorting
+    if (in_lds) {
+        const int P = next_pow2(M < 2 ? 2 : M);
+        for (int i = M + tid; i < P; i += blockDim.x) skeys[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc(skeys, P);
+        n_sorted = M;
+    } else {
+        // radix select of the k-th largest key, 8 bits per pass, most significant byte first
+        if (tid == 0) { sctl[0] = 0ull; sctl[1] = (u64)k; }
+        __syncthreads();
+        for (int byte = 7; byte >= 0; --byte) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const u64 mask = (byte == 7) ? 0ull : (~0ull << ((byte + 1) * 8));
+            const u64 prefix = sctl[0];
+            for (int i = tid; i < M; i += blockDim.x) {
+                const u64 key = gkeys[i];
+                if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> (byte * 8)) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = (int)sctl[1], cum = 0, sel = 0;
+                for (int bin = 255; bin >= 0; --bin) {
+                    const int c = hist[bin];
+                    if (cum + c >= kk) { sel = bin; kk -= cum; break; }
+                    cum += c;
+                }
+                sctl[1] = (u64)kk;
+                sctl[0] = prefix | ((u64)sel << (byte * 8));
+            }
+            __syncthreads();
+        }
+        const u64 kth = sctl[0];
+        int* scnt = (int*)&sctl[2];
+        if (tid == 0) *scnt = 0;
+        __syncthreads();
+        for (int i = tid; i < M; i += blockDim.x) {
+            const u64 key = gkeys[i];
+            if (key >= kth) {
+                const int pos = atomicAdd(scnt, 1);
+                if (pos < SORT_MAX) skeys[pos] = key;
+            }
+        }
+        __syncthreads();
+        int got = *scnt;          // == k because keys are distinct
+        if (got > SORT_MAX) got = SORT_MAX;
+        const int P = next_pow2(got < 2 ? 2 : got);
+        for (int i = got + tid; i < P; i += blockDim.x) skeys[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc(skeys, P);
+        n_sorted = got;
+    }
+    for (int i = tid; i < k; i += blockDim.x) {
+        float s = -INFINITY;
+        int32_t id = 0x7fffffff;
+        if (i < n_sorted) { const u64 key = skeys[i]; s = key_score(key); id = key_id(key); }
+        store_score(o.scores, o.score_dtype, o.row * (long long)k + i, s);
+        o.ids[o.row * (long long)k + i] = id;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_kernel: one block per query of the tile.
+// ---------------------------------------------------------------------------------------------
+struct SelectArgs {
+    const int2* lists;
+    const int* counts;
+    int cap;
+    int scan_grid;          // blocks of the FILTER scan
+    const int32_t* ids;     // [n_rows] passage id of each local row
+    u64* keys_ws;           // [64][keys_stride] global key scratch for M > SORT_MAX
+    long long keys_stride;
+    int k;
+    void* out_scores;
+    int score_dtype;
+    int32_t* out_ids;
+    long long out_row0;     // first output row of this query tile
+    int* status;            // bit0: a candidate list overflowed its cap; bit1: key scratch too small
+    unsigned long long* cand_total;
+};
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 skeys[SORT_MAX];
+    __shared__ int hist[256];
+    __shared__ u64 sctl[4];
+    __shared__ int s_total, s_fill, s_ovf;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int L = a.scan_grid * 4;  // candidate lists of this query
+    auto list_of = [&](int li) -> size_t {
+        return (size_t)(li >> 2) * SCAN_THREADS + (q >> 4) * 64 + (li & 3) * 16 + (q & 15);
+    };
+    if (tid == 0) { s_total = 0; s_fill = 0; s_ovf = 0; }
+    __syncthreads();
+    int mine = 0, ovf = 0;
+    for (int li = tid; li < L; li += SEL_THREADS) {
+        int c = a.counts[list_of(li)];
+        if (c > a.cap) { ovf = 1; c = a.cap; }
+        mine += c;
+    }
+    if (mine) atomicAdd(&s_total, mine);
+    if (ovf) s_ovf = 1;
+    __syncthreads();
+    const int M = s_total;
+    if (tid == 0) {
+        if (s_ovf) atomicOr(a.status, 1);
+        atomicAdd(a.cand_total, (unsigned long long)M);
+    }
+    const bool in_lds = (M <= SORT_MAX);
+    u64* gk = a.keys_ws + (size_t)q * a.keys_stride;
+    if (!in_lds && (long long)M > a.keys_stride) {
+        // cannot happen when the host sized the scratch as lists*cap; report instead of faulting
+        if (tid == 0) atomicOr(a.status, 2);
+        return;
+    }
+    for (int li = tid; li < L; li += SEL_THREADS) {
+        const size_t l = list_of(li);
+        int c = a.counts[l];
+        if (c > a.cap) c = a.cap;
+        if (c == 0) continue;
+        const int base = atomicAdd(&s_fill, c);
+        const int2* src = a.lists + l * (size_t)a.cap;
+        for (int i = 0; i < c; ++i) {
+            const int2 e = src[i];
+            const u64 key = make_key(__int_as_float(e.x), a.ids[e.y]);
+            if (in_lds) skeys[base + i] = key; else gk[base + i] = key;
+        }
+    }
+    __syncthreads();
+    if (!in_lds) __threadfence_block();
+    TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
+    topk_finish(skeys, gk, M, in_lds, hist, sctl, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge_kernel: one block per query; union of n_lists sorted lists of k (score, id) each.
+// Input layout [n_lists, n_q, k].  Pads (id == INT32_MAX) are skipped.
+// ---------------------------------------------------------------------------------------------
+struct MergeArgs {
+    const float* scores;
+    const int32_t* ids;
+    int n_lists;
+    long long n_q;
+    int k;
+    u64* keys_ws;           // [n_q][keys_stride] when n_lists*k > SORT_MAX
+    long long keys_stride;
+    void* out_scores;
+    int score_dtype;
+    int32_t* out_ids;
+    int* status;
+};
+
+__global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 skeys[SORT_MAX];
+    __shared__ int hist[256];
+    __shared__ u64 sctl[4];
+    __shared__ int s_fill;
+    const long long q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int total = a.n_lists * a.k;
+    const bool in_lds = (total <= SORT_MAX);
+    u64* gk = a.keys_ws ? a.keys_ws + (size_t)q * a.keys_stride : nullptr;
+    if (!in_lds && (gk == nullptr || (long long)total > a.keys_stride)) {
+        if (tid == 0) atomicOr(a.status, 2);
+        return;
+    }
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    for (int i = tid; i < total; i += SEL_THREADS) {
+        const int l = i / a.k, j = i - l * a.k;
+        const size_t src = ((size_t)l * a.n_q + q) * a.k + j;
+        const int32_t id = a.ids[src];
+        if (id == 0x7fffffff) continue;
+        const u64 key = make_key(a.scores[src], id);
+        const int pos = atomicAdd(&s_fill, 1);
+        if (in_lds) skeys[pos] = key; else gk[pos] = key;
+    }
+    __syncthreads();
+    if (!in_lds) __threadfence_block();
+    const int M = s_fill;
+    TopkOut o{a.out_scores, a.score_dtype, a.out_ids, q, a.k};
+    topk_finish(skeys, gk, M, in_lds, hist, sctl, o);
+}
+
+}  // namespace artk

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libartmips.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# usage: build.sh [--asm DIR]   (--asm keeps the ISA and resource remarks in DIR)
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../lib"
+mkdir -p "$out"
+flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
+if [ "${1:-}" = "--asm" ]; then
+  tmp="${2:-/tmp/artmips_asm}"
+  mkdir -p "$tmp"
+  (cd "$tmp" && hipcc $flags -save-temps -Rpass-analysis=kernel-resource-usage \
+      -o "$out/libartmips.so" "$here/artmips.hip" 2> "$tmp/resource_usage.txt")
+else
+  hipcc $flags -o "$out/libartmips.so" "$here/artmips.hip"
+fi
+echo "built $out/libartmips.so"

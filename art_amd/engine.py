@@ -1,0 +1,208 @@
+"""MipsEngine: thin Python owner of one libartmips handle.
+
+PyTorch is plumbing here (device memory for queries/results and the current HIP
+stream); all search work happens in the HIP library behind the C ABI.  The
+reference-shaped classes in ``art_amd.art_index`` are built on top of this.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ArtmipsError, check, lib
+
+_TORCH2ABI = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+_NP2ABI = {np.dtype(np.float16): _lib.F16, np.dtype(np.float32): _lib.F32}
+
+
+def _abi_dtype(dt):
+    if dt in _TORCH2ABI:
+        return _TORCH2ABI[dt]
+    raise ValueError("unsupported dtype %r (need float16, bfloat16 or float32)" % (dt,))
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class MipsEngine(object):
+    """Exact MIPS top-k over row shards resident on one or more GPUs.
+
+    devices: list of CUDA(HIP) device indices, one shard per entry (the same index
+    may appear twice).  Defaults to every visible device, as the reference does
+    (art_index.py:204).
+    """
+
+    def __init__(self, dim, storage_dtype=torch.float16, devices=None):
+        if storage_dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("storage dtype must be float16 or bfloat16")
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        if len(devices) < 1:
+            raise RuntimeError("MipsEngine needs at least one GPU; there is no CPU search path")
+        self.dim = int(dim)
+        self.storage_dtype = storage_dtype
+        self.devices = [int(d) for d in devices]
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        check(lib.artmips_create(arr, len(self.devices), self.dim, _abi_dtype(storage_dtype),
+                                 ctypes.byref(self._h)))
+        self.n_rows = 0
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.artmips_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- building ---------------------------------------------------------------------------
+    def begin(self, n_rows):
+        check(lib.artmips_begin(self._h, int(n_rows)))
+        self._building_rows = int(n_rows)
+
+    def upload_host(self, rows, ids):
+        """Append host rows (numpy float16 array, or a CPU torch tensor in the storage dtype)
+        and their int32 passage ids."""
+        if isinstance(rows, np.ndarray):
+            if self.storage_dtype != torch.float16 or rows.dtype != np.float16:
+                raise ValueError("numpy rows must be float16 for a float16 index")
+            rows = np.ascontiguousarray(rows)
+            n, d = rows.shape
+            rows_ptr = rows.ctypes.data
+        else:
+            if rows.device.type != "cpu" or rows.dtype != self.storage_dtype:
+                raise ValueError("host rows must be a CPU tensor of the storage dtype")
+            rows = rows.contiguous()
+            n, d = rows.shape
+            rows_ptr = rows.data_ptr()
+        if d != self.dim:
+            raise ValueError("rows have dim %d, index has dim %d" % (d, self.dim))
+        ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int32)
+        if ids.shape != (n,):
+            raise ValueError("ids must have shape (%d,)" % n)
+        check(lib.artmips_upload(self._h, ctypes.c_void_p(rows_ptr), ctypes.c_void_p(ids.ctypes.data),
+                                 n, 0))
+
+    def upload_device(self, slot, rows, ids, row_offset):
+        """Copy rows already on a GPU into shard `slot` at row_offset (offset inside the shard)."""
+        if rows.dtype != self.storage_dtype or not rows.is_cuda:
+            raise ValueError("device rows must be a CUDA tensor of the storage dtype")
+        if ids.dtype != torch.int32 or not ids.is_cuda:
+            raise ValueError("device ids must be a CUDA int32 tensor")
+        rows = rows.contiguous()
+        ids = ids.contiguous()
+        n, d = rows.shape
+        if d != self.dim or ids.shape != (n,):
+            raise ValueError("shape mismatch")
+        check(lib.artmips_upload_device(self._h, int(slot), ctypes.c_void_p(rows.data_ptr()),
+                                        ctypes.c_void_p(ids.data_ptr()), n, int(row_offset)))
+
+    def finalize(self):
+        check(lib.artmips_finalize(self._h))
+        self.n_rows = self._building_rows
+
+    def build(self, rows, ids):
+        """begin + upload_host + finalize in one call."""
+        self.begin(rows.shape[0])
+        self.upload_host(rows, ids)
+        self.finalize()
+
+    # ---- searching --------------------------------------------------------------------------
+    def _check_queries(self, queries, device_index):
+        if not isinstance(queries, torch.Tensor):
+            raise ValueError("query_embeds must be a torch tensor")
+        if queries.dim() != 2 or queries.shape[1] != self.dim:
+            raise ValueError("query_embeds must have shape [Q, %d], got %s" % (self.dim, tuple(queries.shape)))
+        if queries.shape[0] < 1:
+            raise ValueError("query_embeds is empty")
+        if not queries.is_cuda:
+            raise ValueError("query_embeds must live on a GPU")
+        if queries.device.index != device_index:
+            raise ValueError("query_embeds is on cuda:%d but the index expects cuda:%d"
+                             % (queries.device.index, device_index))
+        _abi_dtype(queries.dtype)
+        return queries.contiguous()
+
+    def search(self, queries, top_k, score_dtype=torch.float16):
+        """(scores [Q,k] score_dtype, ids [Q,k] int32), rows sorted by (score desc, id asc)."""
+        top_k = int(top_k)
+        if top_k < 1 or top_k > self.n_rows:
+            raise ValueError("top_k must be in [1, %d], got %d" % (self.n_rows, top_k))
+        q = self._check_queries(queries, self.devices[0])
+        dev = q.device
+        scores = torch.empty((q.shape[0], top_k), dtype=score_dtype, device=dev)
+        ids = torch.empty((q.shape[0], top_k), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.artmips_search(self._h, ctypes.c_void_p(q.data_ptr()), _abi_dtype(q.dtype),
+                                     q.shape[0], top_k, ctypes.c_void_p(scores.data_ptr()),
+                                     _abi_dtype(score_dtype), ctypes.c_void_p(ids.data_ptr()),
+                                     _stream_ptr(dev)))
+        return scores, ids
+
+    def search_local(self, slot, queries, top_k):
+        """Top-k of one shard: (scores fp32 [Q,k], ids int32 [Q,k]); short shards pad with
+        (-inf, INT32_MAX)."""
+        top_k = int(top_k)
+        if top_k < 1:
+            raise ValueError("top_k must be >= 1")
+        q = self._check_queries(queries, self.devices[slot])
+        dev = q.device
+        scores = torch.empty((q.shape[0], top_k), dtype=torch.float32, device=dev)
+        ids = torch.empty((q.shape[0], top_k), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.artmips_search_local(self._h, int(slot), ctypes.c_void_p(q.data_ptr()),
+                                           _abi_dtype(q.dtype), q.shape[0], top_k,
+                                           ctypes.c_void_p(scores.data_ptr()),
+                                           ctypes.c_void_p(ids.data_ptr()), _stream_ptr(dev)))
+        return scores, ids
+
+    @staticmethod
+    def merge(scores, ids, score_dtype=torch.float16):
+        """k-way merge of [G, Q, k] candidate lists (fp32 scores, int32 ids) on their device."""
+        if scores.dim() != 3 or scores.shape != ids.shape:
+            raise ValueError("scores and ids must both be [G, Q, k]")
+        if scores.dtype != torch.float32 or ids.dtype != torch.int32:
+            raise ValueError("merge takes float32 scores and int32 ids")
+        if not scores.is_cuda or scores.device != ids.device:
+            raise ValueError("merge inputs must live on one GPU")
+        scores = scores.contiguous()
+        ids = ids.contiguous()
+        g, nq, k = scores.shape
+        dev = scores.device
+        out_s = torch.empty((nq, k), dtype=score_dtype, device=dev)
+        out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.artmips_merge(dev.index, ctypes.c_void_p(scores.data_ptr()),
+                                    ctypes.c_void_p(ids.data_ptr()), g, nq, k,
+                                    ctypes.c_void_p(out_s.data_ptr()), _abi_dtype(score_dtype),
+                                    ctypes.c_void_p(out_i.data_ptr()), _stream_ptr(dev)))
+        return out_s, out_i
+
+    def info(self):
+        out = _lib.ArtmipsInfo()
+        check(lib.artmips_info(self._h, ctypes.byref(out)))
+        return {
+            "n_dev": out.n_dev,
+            "dim": out.dim,
+            "storage_dtype": out.storage_dtype,
+            "n_cu": out.n_cu,
+            "n_rows": out.n_rows,
+            "rows_per_shard": [out.rows_per_shard[i] for i in range(out.n_dev)],
+            "index_bytes": out.index_bytes,
+            "workspace_bytes": out.workspace_bytes,
+            "last_scan_ms": out.last_scan_ms,
+            "last_total_ms": out.last_total_ms,
+            "last_scan_launches": out.last_scan_launches,
+            "last_retries": out.last_retries,
+            "last_candidates": out.last_candidates,
+        }
+
+
+__all__ = ["MipsEngine", "ArtmipsError"]

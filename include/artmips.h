@@ -1,0 +1,144 @@
+/*
+ * artmips.h — C ABI of libartmips.so: MI355X-native exact maximum-inner-product
+ * top-k search for ART's evidence index.
+ *
+ * This is the drop-in boundary for the path that the reference implements in
+ * megatron/data/art_index.py (DistributedBruteForceIndex + the store upload that
+ * feeds it).  Every entry point cites the reference lines it replaces.  The
+ * reference is Python, so "the reference's FFI" is a ctypes binding; the stub a
+ * maintainer would add is shown in INTEGRATION.md and shipped as
+ * art_amd/_lib.py.
+ *
+ * Conventions
+ *   - return 0 on success, a negative ARTMIPS_ERR_* on failure; the message of
+ *     the last failure on the calling thread is artmips_last_error().
+ *   - no exceptions cross the ABI, no torch types: plain pointers and sizes.
+ *   - device pointers are raw HIP device addresses (torch: tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (torch:
+ *     torch.cuda.current_stream().cuda_stream); NULL is the default stream.
+ *   - all device work is enqueued on / ordered against `stream`; search entry
+ *     points synchronise that stream before they return (they must read a
+ *     device status word to guarantee exactness).
+ *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
+ *   - passage ids are int32 (the reference returns int32: art_index.py:297).
+ *   - top-k order: score descending, ties broken by LOWER passage id
+ *     (BASELINE.json north_star); scores are fp32-accumulated dot products.
+ */
+#ifndef ARTMIPS_H
+#define ARTMIPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct artmips artmips_t;
+
+/* element types (storage_dtype, q_dtype, score_dtype) */
+enum {
+    ARTMIPS_F16 = 0, /* IEEE half  — the reference's storage type (art_index.py:61,247) */
+    ARTMIPS_BF16 = 1,
+    ARTMIPS_F32 = 2  /* scores out / queries in only; not a storage type yet */
+};
+
+/* error codes */
+enum {
+    ARTMIPS_OK = 0,
+    ARTMIPS_ERR_ARG = -1,         /* bad argument (shape, dtype, k, NULL)           */
+    ARTMIPS_ERR_HIP = -2,         /* a HIP runtime call failed                       */
+    ARTMIPS_ERR_STATE = -3,       /* call sequence error (no index, upload w/o begin) */
+    ARTMIPS_ERR_UNSUPPORTED = -4, /* dim / dtype / k outside what the kernels cover  */
+    ARTMIPS_ERR_NOMEM = -5
+};
+
+#define ARTMIPS_MAX_DEVICES 16
+#define ARTMIPS_MAX_K 2048 /* for indexes larger than ARTMIPS_SORT_MAX rows */
+
+typedef struct artmips_info {
+    int32_t n_dev;                              /* shards (one per device slot)           */
+    int32_t dim;
+    int32_t storage_dtype;
+    int32_t n_cu;                               /* compute units of device slot 0         */
+    int64_t n_rows;                             /* rows in the live index                 */
+    int64_t rows_per_shard[ARTMIPS_MAX_DEVICES];
+    int64_t index_bytes;                        /* bytes of row storage over all shards   */
+    int64_t workspace_bytes;                    /* device scratch currently allocated     */
+    /* timing of the last search call, measured with HIP events on the streams the
+     * kernels were launched on */
+    float last_scan_ms;   /* sum over query tiles of the main scan kernel, slot 0        */
+    float last_total_ms;  /* first kernel start .. last kernel end, slot 0                */
+    int32_t last_scan_launches;
+    int32_t last_retries; /* candidate-list overflow retries taken by the last call      */
+    int64_t last_candidates; /* candidates kept by the filter, summed over queries        */
+} artmips_info_t;
+
+/* Replaces DistributedBruteForceIndex.__init__ (art_index.py:201-209): one handle
+ * owning one row shard per entry of device_ids (art_index.py:204 uses every visible
+ * GPU).  The same device id may be listed more than once (two shards on one GPU);
+ * n_dev == 1 is the per-rank form used by the SPMD path. */
+int artmips_create(const int* device_ids, int n_dev, int dim, int storage_dtype, artmips_t** out);
+
+/* Frees every device buffer.  Replaces `del self.evidence_embeds`
+ * (art_index.py:221,233). */
+void artmips_destroy(artmips_t* h);
+
+/* Start building the next generation of the index with n_rows_total rows, split
+ * into contiguous ceil-div row chunks per shard exactly like torch.chunk
+ * (art_index.py:251-253).  The live index keeps serving until artmips_finalize. */
+int artmips_begin(artmips_t* h, int64_t n_rows_total);
+
+/* Append n_rows host rows (storage dtype) and their passage ids at the upload
+ * cursor of the generation being built; pinned, double-buffered H2D copies.  May
+ * be called repeatedly.  Replaces `np.array(block_embeds)` + `.to('cuda:i')` and
+ * the id_map loop (art_index.py:244-259).  flags: reserved, pass 0. */
+int artmips_upload(artmips_t* h, const void* host_rows, const int32_t* ids, int64_t n_rows,
+                   int flags);
+
+/* Copy n rows that already live on a device into shard `slot` at row_offset
+ * (offset inside that shard).  The index-refresh path without the pickle round
+ * trip (indexer.py:146-165 -> art_index.py:231-265). */
+int artmips_upload_device(artmips_t* h, int slot, const void* dev_rows, const int32_t* dev_ids,
+                          int64_t n, int64_t row_offset);
+
+/* Make the generation being built the live index and free the old one.
+ * Replaces the tail of add_embed_data / update_index (art_index.py:231-265). */
+int artmips_finalize(artmips_t* h);
+
+/* Replaces DistributedBruteForceIndex.search_mips_index (art_index.py:267-304):
+ * exact top-k of q·Eᵀ over every shard, merged on the device of slot 0.
+ *   q_dev       [n_q, dim] on the device of slot 0, dtype q_dtype
+ *   out_scores  [n_q, k]   on the device of slot 0, dtype score_dtype
+ *   out_ids     [n_q, k]   int32 passage ids */
+int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                   void* out_scores, int score_dtype, int32_t* out_ids, void* stream);
+
+/* One shard only: the local top-k a rank contributes in the SPMD path (one
+ * process per GPU).  Outputs are fp32 scores + int32 passage ids on that shard's
+ * device, ready for an RCCL all-gather.  Replaces the per-GPU matmul of
+ * art_index.py:278-280 plus the part of torch.topk (art_index.py:294) that can be
+ * done before the exchange.  If the shard holds fewer than k rows the tail is
+ * filled with (-inf, INT32_MAX). */
+int artmips_search_local(artmips_t* h, int slot, const void* q_dev, int q_dtype, int64_t n_q,
+                         int k, float* out_scores, int32_t* out_ids, void* stream);
+
+/* k-way merge of n_lists candidate lists, each [n_q, k] (fp32 score, int32 id),
+ * laid out [n_lists, n_q, k] as an all-gather leaves them.  Runs on `device`.
+ * Replaces the gather of score slabs to GPU-0 and torch.topk over them
+ * (art_index.py:283-294) with a merge over k*n_lists candidates per query. */
+int artmips_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
+                  int k, void* out_scores, int score_dtype, int32_t* out_ids, void* stream);
+
+/* Shard sizes, memory and the HIP-event timings of the last search. */
+int artmips_info(artmips_t* h, artmips_info_t* out);
+
+/* Message of the last error on this thread ("" if none). */
+const char* artmips_last_error(void);
+
+/* ABI version of this header. */
+int artmips_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTMIPS_H */
