@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: queries/sec of exact top-k over the 21M x 768 evidence index.
+
+A "step" is one end-to-end search call (BASELINE.json config 2, the ART training step:
+64 queries, top-32, 21,015,324 x 768 fp16 rows) with queries already on the device and
+results left on the device.  With --gpus N > 1 (launched by torch.distributed.run, one
+process per GPU) the rows are split into N contiguous shards, every rank searches its
+shard, the (score, id) candidates are all-gathered over RCCL and merged on every rank:
+total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_WIKI = 21015324  # 32 GB fp16 evidence file of the reference README
+DIM = 768
+HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=N_WIKI, help="total evidence rows (default: Wikipedia scale)")
+    p.add_argument("--queries", type=int, default=64)
+    p.add_argument("--topk", type=int, default=32)
+    p.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rows", type=int, default=1000000, help="rows of the CPU baseline sample (config 1)")
+    return p.parse_args()
+
+
+def build_shard(engine, lo, hi, seed, storage):
+    """Synthetic embeddings generated on the device, chunk by chunk: randn / sqrt(768),
+    ids = global row index + 1 (1-based like the reference's evidence ids)."""
+    dev = torch.device("cuda", engine.devices[0])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    engine.begin(hi - lo)
+    chunk = 1 << 18
+    scale = 1.0 / math.sqrt(DIM)
+    for off in range(0, hi - lo, chunk):
+        n = min(chunk, hi - lo - off)
+        rows = (torch.randn((n, DIM), generator=gen, device=dev, dtype=torch.float32) * scale).to(storage)
+        ids = torch.arange(lo + off + 1, lo + off + n + 1, device=dev, dtype=torch.int32)
+        engine.upload_device(0, rows, ids, off)
+    engine.finalize()
+
+
+def cpu_baseline(n_rows, q, k):
+    """The reference's search restated on the host (oracle.reference_restatement =
+    art_index.py:278-294 in fp32) on BASELINE config 1: a bounded sample, ~10-30 s of CPU work."""
+    from oracle import mips_oracle as orc
+
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1234)
+    rows = torch.randn((n_rows, DIM), generator=g, dtype=torch.float32)
+    gq = torch.Generator().manual_seed(4321)
+    queries = torch.randn((q, DIM), generator=gq, dtype=torch.float32)
+    ids = torch.arange(1, n_rows + 1, dtype=torch.int32).numpy()
+    orc.reference_restatement(queries, rows, ids, k)  # warm-up
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        orc.reference_restatement(queries, rows, ids, k)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": q / med,
+        "unit": "queries/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d queries x top-%d over %d x %d fp32 rows (BASELINE config 1), torch.matmul+torch.topk, "
+                  "median of 5 after 1 warm-up; best %.1f q/s; linear extrapolation to %d rows: %.2f q/s"
+                  % (q, k, n_rows, DIM, q / times[0], N_WIKI, q / med * n_rows / N_WIKI),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from art_amd.distributed import engine_spmd_search, shard_bounds
+    from art_amd.engine import MipsEngine
+
+    storage = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    engine = MipsEngine(DIM, storage, [local_rank])
+    lo, hi = shard_bounds(args.rows, world)[rank]
+    build_shard(engine, lo, hi, 1234 + rank, storage)
+
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    queries = torch.randn((args.queries, DIM), generator=gq, device=dev, dtype=torch.float32).to(storage)
+
+    def step():
+        if world == 1:
+            return engine.search(queries, args.topk)
+        return engine_spmd_search(engine, queries, args.topk)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scan_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        scan_ms.append(engine.info()["last_scan_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info = engine.info()
+
+    # sanity: the result is sorted and non-trivial
+    scores, ids = out
+    assert scores.shape == (args.queries, args.topk) and ids.dtype == torch.int32
+    assert bool((scores[:, :-1].float() >= scores[:, 1:].float()).all())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = args.queries * args.steps / elapsed
+        scan_avg_ms = sum(scan_ms) / len(scan_ms)
+        elem = 2
+        alg_bytes = (hi - lo) * DIM * elem  # bytes of rows one launch of the scan kernel must read
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                with open(tfile) as f:
+                    tj = json.load(f)
+                if tj.get("rows") == hi - lo and tj.get("dtype") == args.dtype:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec exact top-k over 21M x 768",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "ART training step: %d queries, top-%d, %d x %d %s rows (BASELINE config 2)"
+                            % (args.queries, args.topk, args.rows, DIM, args.dtype),
+                "rows_total": args.rows,
+                "rows_per_gpu": hi - lo,
+                "queries": args.queries,
+                "top_k": args.topk,
+                "parallelism": "row shards x%d, RCCL all-gather of (score,id) + on-device merge" % world
+                               if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "scan_kernel<FILTER>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms_avg": scan_avg_ms,
+            },
+            "candidates_per_query": info["last_candidates"] / max(1, args.queries),
+            "overflow_retries": info["last_retries"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_rows, 64, 32)
+        print(json.dumps(line), flush=True)
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
