@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -131,26 +132,27 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIM, int NSTAGE>
+template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * 2;
-    static bool attr_done[ARTMIPS_MAX_DEVICES * 4] = {};
+    static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
     if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER>;
-        if (dev < ARTMIPS_MAX_DEVICES * 4 && !attr_done[dev]) {
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX>;
+        if (!attr_done[dev][0]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-            attr_done[dev] = true;
+            attr_done[dev][0] = true;
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX>;
-        if (dev < ARTMIPS_MAX_DEVICES * 4 && !attr_done[dev]) {
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX>;
+        if (!attr_done[dev][1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-            attr_done[dev] = true;
+            attr_done[dev][1] = true;
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
     }
@@ -158,15 +160,35 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     return 0;
 }
 
+// ARTMIPS_SCAN_VARIANT selects an experimental build of the 768-wide f16 scan (tools/scan_sweep.py);
+// unset or 0 is the shipped configuration.
+static int scan_variant() {
+    const char* v = getenv("ARTMIPS_SCAN_VARIANT");
+    return v ? atoi(v) : 0;
+}
+
+// Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
+// DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
 static int launch_scan(int dtype, int dim, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dtype == ARTMIPS_F16) {
-        if (dim == 768) return launch_scan_t<_Float16, 768, 6>(mode, a, grid, st);
-        if (dim == 1024) return launch_scan_t<_Float16, 1024, 4>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<_Float16, 128, 8>(mode, a, grid, st);
+        if (dim == 768) {
+            switch (scan_variant()) {
+                default:
+                case 0: return launch_scan_t<_Float16, 768, 6, 1, 2>(mode, a, grid, st);
+                // experimental builds for tools/scan_sweep.py
+                case 1: return launch_scan_t<_Float16, 768, 6, 0, 2>(mode, a, grid, st);
+                case 2: return launch_scan_t<_Float16, 768, 6, 1, 0>(mode, a, grid, st);
+                case 3: return launch_scan_t<_Float16, 768, 6, 0, 0>(mode, a, grid, st);
+                case 4: return launch_scan_t<_Float16, 768, 3, 1, 2>(mode, a, grid, st);
+                case 5: return launch_scan_t<_Float16, 768, 4, 1, 2>(mode, a, grid, st);
+            }
+        }
+        if (dim == 1024) return launch_scan_t<_Float16, 1024, 4, 1, 2>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<_Float16, 128, 8, 1, 2>(mode, a, grid, st);
     } else if (dtype == ARTMIPS_BF16) {
-        if (dim == 768) return launch_scan_t<__bf16, 768, 6>(mode, a, grid, st);
-        if (dim == 1024) return launch_scan_t<__bf16, 1024, 4>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<__bf16, 128, 8>(mode, a, grid, st);
+        if (dim == 768) return launch_scan_t<__bf16, 768, 6, 1, 2>(mode, a, grid, st);
+        if (dim == 1024) return launch_scan_t<__bf16, 1024, 4, 1, 2>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<__bf16, 128, 8, 1, 2>(mode, a, grid, st);
     }
     return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d storage_dtype=%d", dim, dtype);
 }
@@ -414,7 +436,9 @@ static int round_up_pow2(long long x) {
 static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
     Plan p;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
-    p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu));
+    int grid_mult = 1;
+    if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
+    p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu) * grid_mult);
     const long long tiles_per_block = (p.n_tiles + p.grid - 1) / p.grid;
     const long long cap_max = tiles_per_block * 4;  // rows one lane can ever see
     // pass 0: groups = lanes of the sample scan that share a query = grid0 * 4.  Want >= 8k groups

@@ -120,29 +120,37 @@ struct ScanArgs {
     float* gmax;          // GROUPMAX: [grid*256] running max of each lane
 };
 
-// kappa: which 16-byte chunk (0..7) of a 128-byte column block lane group g = lane>>4 multiplies
-// in MFMA k-step half e.  Any bijection (g,e)->0..7 is numerically valid as long as the row
-// operand and the query operand agree (the dot product is a sum over k in any order); this one
-// makes the ds_read_b128 of the row operand bank-conflict free (DESIGN.md §LDS image).
+// LDS image of a stage (16 rows).  Two layouts are built; both are bank-conflict free for the
+// ds_read_b128 of the MFMA row operand and both rely on the fact that a dot product may sum its
+// k in any order as long as the row operand and the query operand agree on it.
+//
+// LAYOUT 0 ("8x128"): a DMA wave-instruction fetches 8 rows x 128 B.  kappa(g,e) is the 16-byte
+//   chunk (0..7) of a 128-byte column block that lane group g = lane>>4 multiplies in k-step half e.
+// LAYOUT 1 ("linear"): the stage is the 16 rows as they lie in memory (row-major, contiguous), cut
+//   into 1-KiB pieces; a DMA wave-instruction fetches 1 KiB of consecutive addresses.  The low four
+//   bits of every 16-byte chunk index are XORed with the row number, which spreads the 16 rows of a
+//   column over the 16 bank slots.  Lane group g multiplies chunk 4s+g in k-step s (natural order).
 __device__ __forceinline__ int kappa(int g, int e) { return 4 * (g & 1) + 2 * e + (g >> 1); }
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+template <int AUX> __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int DIM, int NSTAGE, int MODE>
+template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
-    constexpr int J = DIM / 64;            // 128-byte column blocks per row
-    constexpr int PIECES = 2 * J;          // 1-KiB pieces per 16-row stage
+    constexpr int KSTEPS = DIM / 32;       // MFMA 16x16x32 k-steps per row
+    constexpr int CPR = DIM / 8;           // 16-byte chunks per row
+    constexpr int PIECES = TILE_ROWS * DIM * 2 / 1024;  // 1-KiB pieces per 16-row stage
     constexpr int PPW = PIECES / 4;        // pieces each of the 4 waves issues per stage
     constexpr int STAGE_BYTES = TILE_ROWS * DIM * 2;
     static_assert(DIM % 128 == 0, "DIM must be a multiple of 128");
+    static_assert(PIECES % 4 == 0, "pieces must split evenly over 4 waves");
     static_assert((NSTAGE - 2) * PPW <= 63, "vmcnt field is 6 bits");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,16 +166,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     const long long n_rows = a.n_rows;
     const long long last_row = n_rows - 1;
 
-    // ---- query operand: 2*J fragments of 8 elements, resident in registers for the whole launch
-    V bq[2 * J];
+    // ---- query operand: KSTEPS fragments of 8 elements, resident in registers for the whole launch
+    V bq[KSTEPS];
     {
         const T* qrow = (const T*)a.qpad + (size_t)(w * 16 + r) * DIM;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                bq[2 * j + e] = *(const V*)(qrow + (8 * j + kappa(g, e)) * 8);
-            }
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
+            bq[s] = *(const V*)(qrow + chunk * 8);
         }
     }
     float thr = 0.0f;
@@ -176,16 +182,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // put a vmcnt(0) inside the streaming loop
     wait_vmcnt<0>();
 #pragma unroll
-    for (int i = 0; i < 2 * J; ++i) asm volatile("" : "+v"(bq[i]));
+    for (int i = 0; i < KSTEPS; ++i) asm volatile("" : "+v"(bq[i]));
     asm volatile("" : "+v"(thr));
 
     // ---- per-lane constants of the LDS image
-    // DMA side: lane i of piece (j, half) fetches row 8*half + (i>>3), chunk 8j + ((i&7) ^ ((i>>3)>>1))
+    // LAYOUT 0, DMA side: lane i of piece (j, half) fetches row 8*half + (i>>3), chunk 8j + ((i&7) ^ ((i>>3)>>1))
     const int rho = lane >> 3;
     const int xch = (lane & 7) ^ (rho >> 1);
-    // MFMA side: lane (r,g) at k-step (j,e) reads slot (r&7)*8 + (kappa(g,e) ^ ((r&7)>>1)) of piece (j, r>>3)
-    const int rd_off0 = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 0) ^ ((r & 7) >> 1))) * 16;
-    const int rd_off1 = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 1) ^ ((r & 7) >> 1))) * 16;
+    // LAYOUT 0, MFMA side: lane (r,g), k-step (j,e): slot (r&7)*8 + (kappa(g,e) ^ ((r&7)>>1)) of piece (j, r>>3)
+    // LAYOUT 1, MFMA side: lane (r,g), k-step s: byte r*ROWBYTES + 256*(s>>2) + 16*((4*(s&3)+g) ^ r)
+    int rd_off[4];
+    if (LAYOUT == 0) {
+        rd_off[0] = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 0) ^ ((r & 7) >> 1))) * 16;
+        rd_off[1] = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 1) ^ ((r & 7) >> 1))) * 16;
+        rd_off[2] = rd_off[3] = 0;
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rd_off[m] = r * (DIM * 2) + 16 * ((4 * m + g) ^ r);
+    }
 
     const long long n_work = a.n_work;
     const long long stride = a.tile_stride;
@@ -202,11 +216,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
             const int p = w * PPW + pp;
-            const int j = p >> 1, half = p & 1;
-            long long row = row0 + 8 * half + rho;
-            if (row > last_row) row = last_row;
-            const T* src = rows + row * DIM + j * 64 + xch * 8;
-            glds16(src, slot_base + p * 1024);
+            const T* src;
+            if (LAYOUT == 0) {
+                const int j = p >> 1, half = p & 1;
+                long long row = row0 + 8 * half + rho;
+                if (row > last_row) row = last_row;
+                src = rows + row * DIM + j * 64 + xch * 8;
+            } else {
+                const int pos = p * 64 + lane;         // 16-byte slot of the stage this lane fills
+                const int trow = pos / CPR;            // row of the tile the slot belongs to
+                const int chunk = (pos - trow * CPR) ^ (trow & 15);
+                long long row = row0 + trow;
+                if (row > last_row) row = last_row;
+                src = rows + row * DIM + chunk * 8;
+            }
+            glds16<AUX>(src, slot_base + p * 1024);
         }
     };
 
@@ -235,18 +259,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 // all row fragments of the stage are requested before the first MFMA, so the LDS
                 // latency is paid once per stage and not once per k-step
-                V af[2 * J];
+                V af[KSTEPS];
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    af[2 * j] = *(const V*)(sb + j * 2048 + rd_off0);
-                    af[2 * j + 1] = *(const V*)(sb + j * 2048 + rd_off1);
+                for (int s = 0; s < KSTEPS; ++s) {
+                    if (LAYOUT == 0) af[s] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
+                    else af[s] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
                 }
 #pragma unroll
-                for (int j = 0; j < 2 * J; ++j) acc = Elem<T>::mfma(af[j], bq[j], acc);
-                // pin the order in the emitted code: 2J ds_read_b128, then 2J MFMAs behind counted
+                for (int s = 0; s < KSTEPS; ++s) acc = Elem<T>::mfma(af[s], bq[s], acc);
+                // pin the order in the emitted code: all ds_read_b128, then the MFMAs behind counted
                 // lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA to save VGPRs)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * J, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * J, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
                 // acc[i] = score(row = tile*16 + g*4 + i, query = w*16 + r)
                 const long long row_base = (b + it * grid) * stride * TILE_ROWS + g * 4;
                 if (MODE == MODE_FILTER) {

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""A/B the experimental builds of the scan kernel in ONE process on ONE index
+(ARTMIPS_SCAN_VARIANT, see launch_scan in art_amd/csrc/artmips.hip): interleaved rounds,
+median and min of the HIP-event time of the FILTER scan per variant."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from art_amd.engine import MipsEngine  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--rows", type=int, default=bench.N_WIKI)
+p.add_argument("--variants", default="0,1,2,3")
+p.add_argument("--rounds", type=int, default=6)
+p.add_argument("--queries", type=int, default=64)
+p.add_argument("--topk", type=int, default=32)
+args = p.parse_args()
+
+eng = MipsEngine(768, torch.float16, [0])
+bench.build_shard(eng, 0, args.rows, 1234, torch.float16)
+g = torch.Generator(device="cuda")
+g.manual_seed(4321)
+q = torch.randn((args.queries, 768), generator=g, device="cuda").half()
+variants = [v for v in args.variants.split(",")]
+times = {v: [] for v in variants}
+totals = {v: [] for v in variants}
+ref = None
+for rnd in range(args.rounds + 1):
+    for v in variants:
+        os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
+        os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
+        s, i = eng.search(q, args.topk, score_dtype=torch.float32)
+        info = eng.info()
+        if rnd > 0:
+            times[v].append(info["last_scan_ms"])
+            totals[v].append(info["last_total_ms"])
+        if ref is None:
+            ref = (s.clone(), i.clone())
+        else:
+            same = bool((i == ref[1]).all())
+            close = bool(torch.allclose(s, ref[0], rtol=1e-4, atol=1e-5))
+            if not (same and close):
+                print("variant %s: ids equal %s, scores close %s  <-- MISMATCH" % (v, same, close), flush=True)
+bytes_ = args.rows * 768 * 2
+for v in variants:
+    t = sorted(times[v])
+    tt = sorted(totals[v])
+    med, mn = t[len(t) // 2], t[0]
+    print("variant %s: scan median %.3f ms (%.0f GB/s)  min %.3f ms (%.0f GB/s)  pipeline median %.3f ms"
+          % (v, med, bytes_ / med / 1e6, mn, bytes_ / mn / 1e6, tt[len(tt) // 2]), flush=True)
