@@ -439,6 +439,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
     int grid_mult = 1;
     if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
     p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu) * grid_mult);
+    p.grid = std::min(p.grid, MAX_LISTS / 4);  // select_kernel keeps one offset per list in LDS
     const long long tiles_per_block = (p.n_tiles + p.grid - 1) / p.grid;
     const long long cap_max = tiles_per_block * 4;  // rows one lane can ever see
     // pass 0: groups = lanes of the sample scan that share a query = grid0 * 4.  Want >= 8k groups
@@ -446,7 +447,9 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
     // of about 1/128 of the rows, but never more than 1/4 of them.
     long long groups = std::max<long long>(1024, 8ll * k);
     long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
-    long long sample = std::max<long long>(grid0, p.n_tiles / 128);
+    long long sample_div = 128;
+    if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
+    long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
     p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
     if (p.pass0) {
         const long long t0 = std::max<long long>(1, sample / grid0);
@@ -501,7 +504,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         a.tile_stride = p.sample_stride;
         int rc = launch_scan(h->dtype, h->dim, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(kth_kernel, dim3(QTILE), dim3(SEL_THREADS), (size_t)p.grid0 * 4 * 4, st,
+        size_t kth_lds = 8;
+        while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
+        hipLaunchKernelGGL(kth_kernel, dim3(QTILE), dim3(SEL_THREADS), kth_lds * 4, st,
                            (const float*)s.gmax.p, p.grid0, k, q_count, (float*)s.thr.p);
         HIP_TRY(hipGetLastError());
     } else {

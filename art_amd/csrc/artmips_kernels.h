@@ -304,19 +304,132 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// selection primitives (one workgroup of SEL_THREADS threads)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// bitonic sort, descending, of P (power of two) keys in LDS
+template <typename K>
+__device__ void bitonic_sort_desc(K* s, int P) {
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += blockDim.x) {
+                const int pos = 2 * i - (i & (stride - 1));
+                const int par = pos + stride;
+                const bool desc = ((pos & size) == 0);
+                const K x = s[pos], y = s[par];
+                if ((x < y) == desc) { s[pos] = y; s[par] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Radix-select helper, run by the first wave after the histogram is complete: walking the 256
+// bins from the top, find the bin in which the running count reaches kk.  Four bins per lane and
+// a wave-wide inclusive scan replace a 256-step serial walk by one thread.
+// Writes sel_out[0] = bin, sel_out[1] = kk minus the count of all higher bins.
+__device__ __forceinline__ void pick_bin_wave(const int* hist, int kk, int* sel_out) {
+    const int lane = threadIdx.x & 63;
+    // lane l owns bins 255-4l .. 252-4l (descending)
+    int c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = hist[255 - 4 * lane - i];
+    const int mine = c[0] + c[1] + c[2] + c[3];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const int excl = incl - mine;
+    if (excl < kk && kk <= incl) {
+        int cum = excl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (cum < kk && kk <= cum + c[i]) { sel_out[0] = 255 - 4 * lane - i; sel_out[1] = kk - cum; }
+            cum += c[i];
+        }
+    }
+}
+
+// k-th largest (1-based k <= n) of n keys, 8 bits per pass from the most significant byte.  Keys
+// may live in LDS or in global memory.  hist: 256 ints of LDS; ctl: 4 ints of LDS.  All threads
+// return the same value.
+template <typename K>
+__device__ K radix_kth(const K* keys, int n, int k, int* hist, int* ctl) {
+    const int tid = threadIdx.x;
+    K prefix = 0;
+    int kk = k;
+    for (int byte = (int)sizeof(K) - 1; byte >= 0; --byte) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const K mask = (byte == (int)sizeof(K) - 1) ? (K)0 : (K)(~(K)0 << ((byte + 1) * 8));
+        for (int i = tid; i < n; i += blockDim.x) {
+            const K key = keys[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> (byte * 8)) & (K)255)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) pick_bin_wave(hist, kk, ctl);
+        __syncthreads();
+        prefix |= (K)ctl[0] << (byte * 8);
+        kk = ctl[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// exclusive prefix sum over the workgroup of one int per thread; wsum: 32 ints of LDS.
+// Returns the exclusive offset of this thread; *total gets the sum over the workgroup.
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        const int nw = blockDim.x >> 6;
+        int x = (tid < nw) ? wsum[tid] : 0;
+        int xi = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(xi, d, 64);
+            if (lane >= d) xi += u;
+        }
+        if (tid < nw) wsum[tid] = xi - x;
+        if (tid == nw - 1) wsum[31] = xi;
+    }
+    __syncthreads();
+    const int off = wsum[wv] + incl - v;
+    *total = wsum[31];
+    __syncthreads();
+    return off;
+}
+
+// ---------------------------------------------------------------------------------------------
 // kth_kernel (pass 0): tau[q] = k-th largest of the per-lane maxima that belong to query q.
 // Each maximum is the score of a distinct row, so k of them >= tau proves that the k-th best
 // score over the whole shard is >= tau: dropping every score < tau loses no top-k member.
-// One block per query slot (64 blocks); dynamic LDS = n_groups * 4 bytes.
+// One block per query slot (64 blocks); dynamic LDS = next_pow2(n_groups) * 4 bytes.
 // ---------------------------------------------------------------------------------------------
+constexpr int KTH_SORT_MAX = 2048;
+
 __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
                                                           int scan_grid, int k, int q_count,
                                                           float* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* vals = (uint32_t*)smem;
     __shared__ int hist[256];
-    __shared__ uint32_t s_prefix;
-    __shared__ int s_kk;
+    __shared__ int ctl[4];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int G = scan_grid * 4;
@@ -332,31 +445,18 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
         const int bb = i >> 2, gg = i & 3;
         vals[i] = f2ord(gmax[(size_t)bb * SCAN_THREADS + (q >> 4) * 64 + gg * 16 + (q & 15)]);
     }
-    if (tid == 0) { s_prefix = 0; s_kk = k; }
-    __syncthreads();
-    for (int byte = 3; byte >= 0; --byte) {
-        if (tid < 256) hist[tid] = 0;
+    uint32_t kth;
+    if (G <= KTH_SORT_MAX) {
+        const int P = next_pow2(G < 2 ? 2 : G);
+        for (int i = G + tid; i < P; i += SEL_THREADS) vals[i] = 0u;
         __syncthreads();
-        const uint32_t mask = (byte == 3) ? 0u : (0xffffffffu << ((byte + 1) * 8));
-        const uint32_t prefix = s_prefix;
-        for (int i = tid; i < G; i += SEL_THREADS) {
-            const uint32_t v = vals[i];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> (byte * 8)) & 255], 1);
-        }
+        bitonic_sort_desc<uint32_t>(vals, P);
+        kth = vals[k - 1];
+    } else {
         __syncthreads();
-        if (tid == 0) {
-            int kk = s_kk, cum = 0, sel = 0;
-            for (int bin = 255; bin >= 0; --bin) {
-                const int c = hist[bin];
-                if (cum + c >= kk) { sel = bin; kk -= cum; break; }
-                cum += c;
-            }
-            s_kk = kk;
-            s_prefix = prefix | ((uint32_t)sel << (byte * 8));
-        }
-        __syncthreads();
+        kth = radix_kth<uint32_t>(vals, G, k, hist, ctl);
     }
-    if (tid == 0) thr[q] = ord2f(s_prefix);
+    if (tid == 0) thr[q] = ord2f(kth);
 }
 
 // thresholds when pass 0 is skipped (small shards): keep everything for real queries
@@ -368,28 +468,7 @@ __global__ void fill_thr_kernel(float* thr, int q_count) {
 // ---------------------------------------------------------------------------------------------
 // exact top-k of a set of distinct 64-bit keys
 // ---------------------------------------------------------------------------------------------
-// bitonic sort, descending, of P (power of two, <= SORT_MAX) keys in LDS
-__device__ void bitonic_sort_desc(u64* s, int P) {
-    const int tid = threadIdx.x;
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (P >> 1); i += blockDim.x) {
-                const int pos = 2 * i - (i & (stride - 1));
-                const int par = pos + stride;
-                const bool desc = ((pos & size) == 0);
-                const u64 x = s[pos], y = s[par];
-                if ((x < y) == desc) { s[pos] = y; s[par] = x; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int x) {
-    int p = 1;
-    while (p < x) p <<= 1;
-    return p;
-}
+constexpr int SUB_MAX = 2048;   // keys of the second-level sample / survivor buffer (16 KiB)
 
 struct TopkOut {
     void* scores;     // [*, k] score_dtype
@@ -399,83 +478,106 @@ struct TopkOut {
     int k;
 };
 
-// Keys are either already in LDS (M <= SORT_MAX, unsorted, in skeys[0..M)) or in global memory
-// gkeys[0..M).  Writes the k best in order; slots beyond M get (-inf, INT32_MAX).
-// hist: 256 ints of LDS, sctl: 4 x u64 of LDS.
-__device__ void topk_finish(u64* skeys, const u64* gkeys, int M, bool in_lds, int* hist, u64* sctl,
-                            const TopkOut& o) {
-    const int tid = threadIdx.x;
-    const int k = o.k;
-    int n_sorted;  // number of real keys in skeys after sorting
-    if (in_lds) {
-        const int P = next_pow2(M < 2 ? 2 : M);
-        for (int i = M + tid; i < P; i += blockDim.x) skeys[i] = 0ull;
-        __syncthreads();
-        bitonic_sort_desc(skeys, P);
-        n_sorted = M;
-    } else {
-        // radix select of the k-th largest key, 8 bits per pass, most significant byte first
-        if (tid == 0) { sctl[0] = 0ull; sctl[1] = (u64)k; }
-        __syncthreads();
-        for (int byte = 7; byte >= 0; --byte) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const u64 mask = (byte == 7) ? 0ull : (~0ull << ((byte + 1) * 8));
-            const u64 prefix = sctl[0];
-            for (int i = tid; i < M; i += blockDim.x) {
-                const u64 key = gkeys[i];
-                if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> (byte * 8)) & 255ull)], 1);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int kk = (int)sctl[1], cum = 0, sel = 0;
-                for (int bin = 255; bin >= 0; --bin) {
-                    const int c = hist[bin];
-                    if (cum + c >= kk) { sel = bin; kk -= cum; break; }
-                    cum += c;
-                }
-                sctl[1] = (u64)kk;
-                sctl[0] = prefix | ((u64)sel << (byte * 8));
-            }
-            __syncthreads();
-        }
-        const u64 kth = sctl[0];
-        int* scnt = (int*)&sctl[2];
-        if (tid == 0) *scnt = 0;
-        __syncthreads();
-        for (int i = tid; i < M; i += blockDim.x) {
-            const u64 key = gkeys[i];
-            if (key >= kth) {
-                const int pos = atomicAdd(scnt, 1);
-                if (pos < SORT_MAX) skeys[pos] = key;
-            }
-        }
-        __syncthreads();
-        int got = *scnt;          // == k because keys are distinct
-        if (got > SORT_MAX) got = SORT_MAX;
-        const int P = next_pow2(got < 2 ? 2 : got);
-        for (int i = got + tid; i < P; i += blockDim.x) skeys[i] = 0ull;
-        __syncthreads();
-        bitonic_sort_desc(skeys, P);
-        n_sorted = got;
-    }
-    for (int i = tid; i < k; i += blockDim.x) {
+struct TopkScratch {
+    u64* skeys;   // SORT_MAX keys of LDS
+    u64* sub;     // SUB_MAX keys of LDS
+    int* hist;    // 256 ints
+    int* ctl;     // 4 ints
+};
+
+__device__ __forceinline__ void write_topk(const u64* sorted, int n_sorted, const TopkOut& o) {
+    for (int i = threadIdx.x; i < o.k; i += blockDim.x) {
         float s = -INFINITY;
         int32_t id = 0x7fffffff;
-        if (i < n_sorted) { const u64 key = skeys[i]; s = key_score(key); id = key_id(key); }
-        store_score(o.scores, o.score_dtype, o.row * (long long)k + i, s);
-        o.ids[o.row * (long long)k + i] = id;
+        if (i < n_sorted) { const u64 key = sorted[i]; s = key_score(key); id = key_id(key); }
+        store_score(o.scores, o.score_dtype, o.row * (long long)o.k + i, s);
+        o.ids[o.row * (long long)o.k + i] = id;
     }
+}
+
+// The M keys are in keys[0..M): in LDS (== sc.skeys) when in_lds, else in global memory.
+// Writes the k best in order; output slots beyond M get (-inf, INT32_MAX).
+//
+// Three routes, all exact:
+//   two-level  (small k, many keys): sort a sample of the first ns keys, take its k-th as a second
+//              lower bound, keep the few keys above it, sort those;
+//   full sort  (M <= SORT_MAX keys in LDS);
+//   radix      (keys in global memory): radix-select the k-th key, gather the k keys above it, sort.
+__device__ void topk_finish(const u64* keys, int M, bool in_lds, const TopkScratch& sc, const TopkOut& o) {
+    const int tid = threadIdx.x;
+    const int k = o.k;
+    if (M <= 0) { write_topk(sc.sub, 0, o); return; }
+    // ---- two-level route
+    int ns = next_pow2(4 * k);
+    if (ns < 512) ns = 512;
+    if (ns <= SUB_MAX && M >= 4 * ns) {
+        for (int i = tid; i < ns; i += blockDim.x) sc.sub[i] = keys[i];
+        __syncthreads();
+        bitonic_sort_desc<u64>(sc.sub, ns);
+        const u64 bound = sc.sub[k - 1];   // k sampled keys are >= bound, so is the true k-th key
+        __syncthreads();
+        if (tid == 0) sc.ctl[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < M; i += blockDim.x) {
+            const u64 key = keys[i];
+            if (key >= bound) {
+                const int pos = atomicAdd(&sc.ctl[0], 1);
+                if (pos < SUB_MAX) sc.sub[pos] = key;
+            }
+        }
+        __syncthreads();
+        const int got = sc.ctl[0];
+        __syncthreads();
+        if (got <= SUB_MAX) {
+            const int P = next_pow2(got < 2 ? 2 : got);
+            for (int i = got + tid; i < P; i += blockDim.x) sc.sub[i] = 0ull;
+            __syncthreads();
+            bitonic_sort_desc<u64>(sc.sub, P);
+            write_topk(sc.sub, got, o);
+            return;
+        }
+        // too many survivors (skewed sample): fall through to the unconditional routes
+    }
+    if (in_lds) {
+        const int P = next_pow2(M < 2 ? 2 : M);
+        for (int i = M + tid; i < P; i += blockDim.x) sc.skeys[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc<u64>(sc.skeys, P);
+        write_topk(sc.skeys, M, o);
+        return;
+    }
+    // ---- radix route over global keys (k <= SORT_MAX)
+    const int kk = k < M ? k : M;
+    const u64 kth = radix_kth<u64>(keys, M, kk, sc.hist, sc.ctl);
+    if (tid == 0) sc.ctl[2] = 0;
+    __syncthreads();
+    for (int i = tid; i < M; i += blockDim.x) {
+        const u64 key = keys[i];
+        if (key >= kth) {
+            const int pos = atomicAdd(&sc.ctl[2], 1);
+            if (pos < SORT_MAX) sc.skeys[pos] = key;
+        }
+    }
+    __syncthreads();
+    int got = sc.ctl[2];  // == kk because keys are distinct
+    if (got > SORT_MAX) got = SORT_MAX;
+    const int P = next_pow2(got < 2 ? 2 : got);
+    for (int i = got + tid; i < P; i += blockDim.x) sc.skeys[i] = 0ull;
+    __syncthreads();
+    bitonic_sort_desc<u64>(sc.skeys, P);
+    write_topk(sc.skeys, got, o);
 }
 
 // ---------------------------------------------------------------------------------------------
 // select_kernel: one block per query of the tile.
 // ---------------------------------------------------------------------------------------------
+constexpr int MAX_LISTS = 4096;  // candidate lists per query = scan grid * 4 (grid <= 1024)
+
 struct SelectArgs {
     const int2* lists;
     const int* counts;
     int cap;
-    int scan_grid;          // blocks of the FILTER scan
+    int scan_grid;          // blocks of the FILTER scan (<= 1024)
     const int32_t* ids;     // [n_rows] passage id of each local row
     u64* keys_ws;           // [64][keys_stride] global key scratch for M > SORT_MAX
     long long keys_stride;
@@ -490,31 +592,42 @@ struct SelectArgs {
 
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     __shared__ __attribute__((aligned(16))) u64 skeys[SORT_MAX];
+    __shared__ __attribute__((aligned(16))) u64 sub[SUB_MAX];
+    __shared__ int loff[MAX_LISTS + 1];
     __shared__ int hist[256];
-    __shared__ u64 sctl[4];
-    __shared__ int s_total, s_fill, s_ovf;
+    __shared__ int ctl[4];
+    __shared__ int wsum[32];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int L = a.scan_grid * 4;  // candidate lists of this query
     auto list_of = [&](int li) -> size_t {
         return (size_t)(li >> 2) * SCAN_THREADS + (q >> 4) * 64 + (li & 3) * 16 + (q & 15);
     };
-    if (tid == 0) { s_total = 0; s_fill = 0; s_ovf = 0; }
-    __syncthreads();
+    // ---- exclusive offsets of the lists: thread t owns lists [t*per, t*per+per)
+    const int per = (L + SEL_THREADS - 1) / SEL_THREADS;  // <= 4
+    int c[4] = {0, 0, 0, 0};
     int mine = 0, ovf = 0;
-    for (int li = tid; li < L; li += SEL_THREADS) {
-        int c = a.counts[list_of(li)];
-        if (c > a.cap) { ovf = 1; c = a.cap; }
-        mine += c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int li = tid * per + i;
+        if (i < per && li < L) {
+            int v = a.counts[list_of(li)];
+            if (v > a.cap) { ovf = 1; v = a.cap; }
+            c[i] = v;
+            mine += v;
+        }
     }
-    if (mine) atomicAdd(&s_total, mine);
-    if (ovf) s_ovf = 1;
+    int M;
+    int off = block_excl_scan(mine, wsum, &M);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int li = tid * per + i;
+        if (i < per && li < L) { loff[li] = off; off += c[i]; }
+    }
+    if (tid == 0) loff[L] = M;
+    if (ovf) atomicOr(a.status, 1);
+    if (tid == 0) atomicAdd(a.cand_total, (unsigned long long)M);
     __syncthreads();
-    const int M = s_total;
-    if (tid == 0) {
-        if (s_ovf) atomicOr(a.status, 1);
-        atomicAdd(a.cand_total, (unsigned long long)M);
-    }
     const bool in_lds = (M <= SORT_MAX);
     u64* gk = a.keys_ws + (size_t)q * a.keys_stride;
     if (!in_lds && (long long)M > a.keys_stride) {
@@ -522,23 +635,22 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         if (tid == 0) atomicOr(a.status, 2);
         return;
     }
-    for (int li = tid; li < L; li += SEL_THREADS) {
-        const size_t l = list_of(li);
-        int c = a.counts[l];
-        if (c > a.cap) c = a.cap;
-        if (c == 0) continue;
-        const int base = atomicAdd(&s_fill, c);
-        const int2* src = a.lists + l * (size_t)a.cap;
-        for (int i = 0; i < c; ++i) {
-            const int2 e = src[i];
-            const u64 key = make_key(__int_as_float(e.x), a.ids[e.y]);
-            if (in_lds) skeys[base + i] = key; else gk[base + i] = key;
+    // ---- balanced gather: candidate e of the query lives in the list found by binary search over
+    // the offsets; every thread handles M/1024 candidates with independent loads
+    u64* dst = in_lds ? skeys : gk;
+    for (int e = tid; e < M; e += SEL_THREADS) {
+        int lo = 0, hi = L;  // invariant: loff[lo] <= e < loff[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (loff[mid] <= e) lo = mid; else hi = mid;
         }
+        const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+        dst[e] = make_key(__int_as_float(ent.x), a.ids[ent.y]);
     }
     __syncthreads();
-    if (!in_lds) __threadfence_block();
+    TopkScratch sc{skeys, sub, hist, ctl};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
-    topk_finish(skeys, gk, M, in_lds, hist, sctl, o);
+    topk_finish(dst, M, in_lds, sc, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,8 +673,9 @@ struct MergeArgs {
 
 __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     __shared__ __attribute__((aligned(16))) u64 skeys[SORT_MAX];
+    __shared__ __attribute__((aligned(16))) u64 sub[SUB_MAX];
     __shared__ int hist[256];
-    __shared__ u64 sctl[4];
+    __shared__ int ctl[4];
     __shared__ int s_fill;
     const long long q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -575,20 +688,20 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     }
     if (tid == 0) s_fill = 0;
     __syncthreads();
+    u64* dst = in_lds ? skeys : gk;
     for (int i = tid; i < total; i += SEL_THREADS) {
         const int l = i / a.k, j = i - l * a.k;
         const size_t src = ((size_t)l * a.n_q + q) * a.k + j;
         const int32_t id = a.ids[src];
         if (id == 0x7fffffff) continue;
         const u64 key = make_key(a.scores[src], id);
-        const int pos = atomicAdd(&s_fill, 1);
-        if (in_lds) skeys[pos] = key; else gk[pos] = key;
+        dst[atomicAdd(&s_fill, 1)] = key;
     }
     __syncthreads();
-    if (!in_lds) __threadfence_block();
     const int M = s_fill;
+    TopkScratch sc{skeys, sub, hist, ctl};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, q, a.k};
-    topk_finish(skeys, gk, M, in_lds, hist, sctl, o);
+    topk_finish(dst, M, in_lds, sc, o);
 }
 
 }  // namespace artk
