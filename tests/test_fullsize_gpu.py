@@ -1,0 +1,99 @@
+"""Full-size (21,015,324 x 768 fp16, BASELINE config 2) checks through size-independent properties:
+planted winners at known rows must come back in the planted order, the rest of the list must agree
+with an independent chunked torch reference, and a 4-shard split of the same rows must return the
+same ids."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N = 21015324
+DIM = 768
+
+
+@pytest.fixture(scope="module")
+def big():
+    from art_amd.engine import MipsEngine
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    queries = torch.randn((64, DIM), generator=g, device=dev).half()
+    # planted rows: first, last, around the 4- and 8-way shard boundaries, inside the last partial tile
+    chunk8 = -(-N // 8)
+    planted = [0, N - 1, N - 3, chunk8 - 1, chunk8, 2 * chunk8 - 1, 4 * chunk8, 7 * chunk8, 12345677]
+    eng = MipsEngine(DIM, torch.float16, [0])
+    eng4 = MipsEngine(DIM, torch.float16, [0, 0, 0, 0])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    chunk4 = -(-N // 4)
+    eng.begin(N)
+    eng4.begin(N)
+    step = 1 << 18
+    best_s = torch.full((64, 40), -float("inf"), device=dev)
+    best_i = torch.zeros((64, 40), dtype=torch.int64, device=dev)
+    for off in range(0, N, step):
+        n = min(step, N - off)
+        rows = (torch.randn((n, DIM), generator=gen, device=dev) * (1.0 / math.sqrt(DIM))).half()
+        for j, p in enumerate(planted):
+            if off <= p < off + n:
+                # query j's own direction, scaled so that the score (~768 * scale) beats every random row
+                rows[p - off] = (queries[j].float() * (0.02 + 0.001 * j)).half()
+        ids = torch.arange(off + 1, off + n + 1, device=dev, dtype=torch.int32)
+        eng.upload_device(0, rows, ids, off)
+        # the same rows into the 4-shard engine (a chunk may straddle a shard boundary)
+        pos = off
+        while pos < off + n:
+            slot = pos // chunk4
+            end = min(off + n, (slot + 1) * chunk4)
+            eng4.upload_device(slot, rows[pos - off:end - off], ids[pos - off:end - off], pos - slot * chunk4)
+            pos = end
+        # independent reference: rocBLAS matmul (fp32 accumulate) + running torch.topk
+        s = rows.float() @ queries.float().T
+        cs, ci = torch.topk(s.T, 40, dim=1)
+        cat_s = torch.cat([best_s, cs], 1)
+        cat_i = torch.cat([best_i, ci + off + 1], 1)
+        o = torch.argsort(cat_s, dim=1, descending=True, stable=True)[:, :40]
+        best_s, best_i = torch.gather(cat_s, 1, o), torch.gather(cat_i, 1, o)
+        del rows, s
+    eng.finalize()
+    eng4.finalize()
+    yield eng, eng4, queries, planted, best_s, best_i
+    eng.close()
+    eng4.close()
+
+
+def test_planted_winners_and_reference(big):
+    eng, eng4, queries, planted, ref_s, ref_i = big
+    s, i = eng.search(queries, 32, score_dtype=torch.float32)
+    assert eng.info()["last_retries"] == 0
+    for j, p in enumerate(planted):
+        assert int(i[j, 0]) == p + 1, "planted row %d not first for query %d" % (p, j)
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    # against the torch reference: same ids wherever neighbouring reference scores are > 1e-5 apart
+    gap = (ref_s[:, :33][:, :-1] - ref_s[:, :33][:, 1:])
+    clear = (gap[:, :32] > 1e-4) & (torch.cat([torch.ones_like(gap[:, :1]), gap[:, :31]], 1) > 1e-4)
+    assert clear.float().mean() > 0.9
+    assert bool((i.long()[clear] == ref_i[:, :32][clear]).all())
+    assert torch.allclose(s, ref_s[:, :32], rtol=1e-3, atol=1e-4)
+
+
+def test_four_shards_equal_one(big):
+    eng, eng4, queries, planted, ref_s, ref_i = big
+    s1, i1 = eng.search(queries, 32, score_dtype=torch.float32)
+    s4, i4 = eng4.search(queries, 32, score_dtype=torch.float32)
+    assert eng4.info()["rows_per_shard"] == [5253831, 5253831, 5253831, 5253831]
+    assert torch.equal(i1, i4) and torch.equal(s1, s4)
+
+
+def test_eval_shape_k100_q16(big):
+    # evaluate.py's call shape: 16 queries, top-100
+    eng, eng4, queries, planted, ref_s, ref_i = big
+    s, i = eng.search(queries[:16], 100, score_dtype=torch.float32)
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    assert bool((i.long()[:, :32] == ref_i[:16, :32]).float().mean() > 0.95)
+    for j in range(9):
+        assert int(i[j, 0]) == planted[j] + 1
