@@ -132,7 +132,7 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX>
+template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * 2;
     static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
@@ -140,7 +140,7 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
     if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ>;
         if (!attr_done[dev][0]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -148,7 +148,7 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ>;
         if (!attr_done[dev][1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -169,29 +169,48 @@ static int scan_variant() {
 
 // Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
 // DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
-static int launch_scan(int dtype, int dim, int mode, const ScanArgs& a, int grid, hipStream_t st) {
-    if (dtype == ARTMIPS_F16) {
-        if (dim == 768) {
-            switch (scan_variant()) {
-                default:
-                case 0: return launch_scan_t<_Float16, 768, 6, 1, 2>(mode, a, grid, st);
-                // experimental builds for tools/scan_sweep.py
-                case 1: return launch_scan_t<_Float16, 768, 6, 0, 2>(mode, a, grid, st);
-                case 2: return launch_scan_t<_Float16, 768, 6, 1, 0>(mode, a, grid, st);
-                case 3: return launch_scan_t<_Float16, 768, 6, 0, 0>(mode, a, grid, st);
-                case 4: return launch_scan_t<_Float16, 768, 3, 1, 2>(mode, a, grid, st);
-                case 5: return launch_scan_t<_Float16, 768, 4, 1, 2>(mode, a, grid, st);
+template <typename T>
+static int launch_scan_dt(int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
+    if (dim == 768) {
+        if (nq == 1) {
+            if (sizeof(T) == 2 && scan_variant() != 0) {
+                switch (scan_variant()) {  // experimental builds for tools/scan_sweep.py
+                    case 1: return launch_scan_t<T, 768, 6, 0, 2>(mode, a, grid, st);
+                    case 2: return launch_scan_t<T, 768, 6, 1, 0>(mode, a, grid, st);
+                    case 3: return launch_scan_t<T, 768, 6, 0, 0>(mode, a, grid, st);
+                    case 4: return launch_scan_t<T, 768, 3, 1, 2>(mode, a, grid, st);
+                    default: break;
+                }
             }
+            return launch_scan_t<T, 768, 6, 1, 2, 1>(mode, a, grid, st);
         }
-        if (dim == 1024) return launch_scan_t<_Float16, 1024, 4, 1, 2>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<_Float16, 128, 8, 1, 2>(mode, a, grid, st);
-    } else if (dtype == ARTMIPS_BF16) {
-        if (dim == 768) return launch_scan_t<__bf16, 768, 6, 1, 2>(mode, a, grid, st);
-        if (dim == 1024) return launch_scan_t<__bf16, 1024, 4, 1, 2>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<__bf16, 128, 8, 1, 2>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 768, 6, 1, 2, 3>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 768, 6, 1, 2, 4>(mode, a, grid, st);
     }
-    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d storage_dtype=%d", dim, dtype);
+    if (dim == 1024) {
+        if (nq == 1) return launch_scan_t<T, 1024, 4, 1, 2, 1>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 1024, 4, 1, 2, 2>(mode, a, grid, st);
+    }
+    if (dim == 128) {
+        if (nq == 1) return launch_scan_t<T, 128, 8, 1, 2, 1>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 128, 8, 1, 2, 2>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 128, 8, 1, 2, 3>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 128, 8, 1, 2, 4>(mode, a, grid, st);
+    }
+    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d nq=%d", dim, nq);
 }
+
+// Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
+// DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
+static int launch_scan(int dtype, int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
+    if (dtype == ARTMIPS_F16) return launch_scan_dt<_Float16>(dim, nq, mode, a, grid, st);
+    if (dtype == ARTMIPS_BF16) return launch_scan_dt<__bf16>(dim, nq, mode, a, grid, st);
+    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for storage_dtype=%d", dtype);
+}
+
+// column groups per pass the kernels are built for at this width
+static int max_nq(int dim) { return dim == 1024 ? 2 : MAX_NQ; }
 
 static bool dim_supported(int dim) { return dim == 768 || dim == 1024 || dim == 128; }
 
@@ -425,6 +444,7 @@ struct Plan {
     int grid;             // blocks of the FILTER scan
     int cap;              // entries per candidate list
     long long n_tiles;
+    int nq;               // column groups (of 64 queries) per scan pass
 };
 
 static int round_up_pow2(long long x) {
@@ -433,8 +453,9 @@ static int round_up_pow2(long long x) {
     return (int)std::min<long long>(p, 1ll << 30);
 }
 
-static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
+static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int nq) {
     Plan p;
+    p.nq = nq;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     int grid_mult = 1;
     if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
@@ -447,7 +468,10 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
     // of about 1/128 of the rows, but never more than 1/4 of them.
     long long groups = std::max<long long>(1024, 8ll * k);
     long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
-    long long sample_div = 128;
+    // sample = n_tiles / sample_div.  A larger sample costs pass-0 time but tightens tau, and every
+    // survivor costs the main scan time too (profiles/r01_e_sample_sweep.txt): 1/64 of the rows is
+    // the measured optimum at k = 32..100, 1/16 at k = 1000.
+    long long sample_div = (k <= 128) ? 64 : (k <= 512) ? 32 : 16;
     if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
     long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
     p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
@@ -473,9 +497,10 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost) {
 }
 
 template <typename T>
-static void launch_pack(const void* q, int q_dtype, int q_count, int dim, void* out, hipStream_t st) {
-    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(64), dim3(256), 0, st, q, q_dtype, q_count, dim,
-                       (T*)out);
+static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int dim, void* out,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(64 * (q_tile / QGROUP)), dim3(256), 0, st, q, q_dtype,
+                       q_count, q_tile, dim, (T*)out);
 }
 
 // Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
@@ -483,8 +508,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
                         int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
                         long long out_row0, hipStream_t st, int tile_index) {
     const Generation& gen = s.live;
-    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, h->dim, s.qpad.p, st);
-    else launch_pack<__bf16>(q_tile, q_dtype, q_count, h->dim, s.qpad.p, st);
+    const int qt = p.nq * QGROUP;
+    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+    else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
     HIP_TRY(hipGetLastError());
 
     ScanArgs a;
@@ -502,15 +528,15 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     if (p.pass0) {
         a.n_work = p.n_sample;
         a.tile_stride = p.sample_stride;
-        int rc = launch_scan(h->dtype, h->dim, MODE_GROUPMAX, a, p.grid0, st);
+        int rc = launch_scan(h->dtype, h->dim, p.nq, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
         size_t kth_lds = 8;
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
-        hipLaunchKernelGGL(kth_kernel, dim3(QTILE), dim3(SEL_THREADS), kth_lds * 4, st,
-                           (const float*)s.gmax.p, p.grid0, k, q_count, (float*)s.thr.p);
+        hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(SEL_THREADS), kth_lds * 4, st,
+                           (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p);
         HIP_TRY(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(64), 0, st, (float*)s.thr.p, q_count);
+        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, (float*)s.thr.p, q_count, qt);
         HIP_TRY(hipGetLastError());
     }
 
@@ -522,7 +548,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         s.ev_scan.push_back(e);
     }
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
-    int rc = launch_scan(h->dtype, h->dim, MODE_FILTER, a, p.grid, st);
+    int rc = launch_scan(h->dtype, h->dim, p.nq, MODE_FILTER, a, p.grid, st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
 
@@ -532,9 +558,10 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     sa.counts = (const int*)s.counts.p;
     sa.cap = p.cap;
     sa.scan_grid = p.grid;
+    sa.nq = p.nq;
     sa.ids = gen.ids;
     sa.keys_ws = (u64*)s.keys.p;
-    sa.keys_stride = (long long)(s.keys.bytes / 8 / QTILE);
+    sa.keys_stride = (long long)(s.keys.bytes / 8 / (size_t)qt);
     sa.k = k;
     sa.out_scores = out_scores;
     sa.score_dtype = score_dtype;
@@ -561,26 +588,30 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
     const size_t q_row_bytes = (size_t)h->dim * elem_size(q_dtype);
     int retries = 0;
     for (;;) {
-        Plan p = make_plan(s, gen.n_rows, k, h->cap_boost);
+        // up to 256 queries share one sweep over the rows (4 column groups of 64)
+        int nq = (int)std::min<int64_t>((n_q + QGROUP - 1) / QGROUP, max_nq(h->dim));
+        if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
+        const int QT = nq * QGROUP;
+        Plan p = make_plan(s, gen.n_rows, k, h->cap_boost, nq);
         // workspace
         int rc = 0;
-        if ((rc = ensure(s.qpad, (size_t)QTILE * h->dim * 2))) return rc;
-        if ((rc = ensure(s.thr, QTILE * 4))) return rc;
+        if ((rc = ensure(s.qpad, (size_t)QT * h->dim * 2))) return rc;
+        if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
         if ((rc = ensure(s.status, 64))) return rc;
-        if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * SCAN_THREADS * 4))) return rc;
-        if ((rc = ensure(s.counts, (size_t)p.grid * SCAN_THREADS * 4))) return rc;
-        const size_t list_entries = (size_t)p.grid * SCAN_THREADS * (size_t)p.cap;
+        if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * SCAN_THREADS * 4))) return rc;
+        if ((rc = ensure(s.counts, (size_t)p.grid * nq * SCAN_THREADS * 4))) return rc;
+        const size_t list_entries = (size_t)p.grid * nq * SCAN_THREADS * (size_t)p.cap;
         if ((rc = ensure(s.lists, list_entries * 8))) return rc;
         // global key scratch: worst case every list of a query is full
         const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
         if (keys_per_q > (size_t)SORT_MAX) {
-            if ((rc = ensure(s.keys, keys_per_q * 8 * QTILE))) return rc;
+            if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
         }
         HIP_TRY(hipMemsetAsync(s.status.p, 0, 64, st));
         if (record_stats) HIP_TRY(hipEventRecord(s.ev_t0, st));
         int n_tiles_q = 0;
-        for (int64_t q0 = 0; q0 < n_q; q0 += QTILE, ++n_tiles_q) {
-            const int qc = (int)std::min<int64_t>(QTILE, n_q - q0);
+        for (int64_t q0 = 0; q0 < n_q; q0 += QT, ++n_tiles_q) {
+            const int qc = (int)std::min<int64_t>(QT, n_q - q0);
             rc = enqueue_tile(h, s, p, (const char*)q_dev + (size_t)q0 * q_row_bytes, q_dtype, qc, k,
                               out_scores, score_dtype, out_ids, q0, st, n_tiles_q);
             if (rc) return rc;

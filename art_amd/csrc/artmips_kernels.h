@@ -30,7 +30,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
-constexpr int QTILE = 64;        // queries per scan pass (4 waves x 16 MFMA columns)
+constexpr int QGROUP = 64;       // queries per column group (4 waves x 16 MFMA columns)
+constexpr int MAX_NQ = 4;        // column groups per scan pass: a pass scores up to 256 queries
 constexpr int SCAN_THREADS = 256;
 constexpr int TILE_ROWS = 16;    // rows per LDS stage (one 16x16x32 MFMA row block)
 constexpr int SORT_MAX = 8192;   // 64-bit keys sorted in LDS by select/merge (64 KiB)
@@ -48,6 +49,19 @@ template <> struct Elem<_Float16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+    // inline-asm forms used when the query operand must live in the accumulator register file.
+    // The leading s_nop 1 is the VALU-write -> MFMA-operand-read hazard pad: hipcc may re-materialise
+    // an operand (v_mov / v_accvgpr_read) right in front of the statement and pads nothing inside asm.
+    template <bool B_AGPR, bool FIRST>
+    static __device__ __forceinline__ void mfma_asm(f32x4& c, const V& a, const V& b) {
+        if constexpr (FIRST) {
+            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+        } else {
+            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        }
+    }
 };
 template <> struct Elem<__bf16> {
     typedef bf16x8 V;
@@ -55,6 +69,16 @@ template <> struct Elem<__bf16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
+    template <bool B_AGPR, bool FIRST>
+    static __device__ __forceinline__ void mfma_asm(f32x4& c, const V& a, const V& b) {
+        if constexpr (FIRST) {
+            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+        } else {
+            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        }
+    }
 };
 
 // Orderable 32-bit image of a float: larger float <=> larger unsigned. -0 is folded into +0 so
@@ -85,12 +109,12 @@ __device__ __forceinline__ void store_score(void* out, int dtype, int64_t idx, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// pack_queries_kernel: [q_count, dim] (f16 / bf16 / f32) -> [64, dim] storage dtype, zero padded.
+// pack_queries_kernel: [q_count, dim] (f16 / bf16 / f32) -> [q_tile, dim] storage dtype, zero padded.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_queries_kernel(const void* __restrict__ q, int q_dtype, int q_count, int dim,
-                                    T* __restrict__ out) {
-    const int total = QTILE * dim;
+__global__ void pack_queries_kernel(const void* __restrict__ q, int q_dtype, int q_count, int q_tile,
+                                    int dim, T* __restrict__ out) {
+    const int total = q_tile * dim;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / dim;
         float v = 0.0f;
@@ -111,13 +135,13 @@ struct ScanArgs {
     long long n_rows;
     long long n_work;     // tiles (or sample tiles) to visit in this launch
     long long tile_stride;// actual tile = work index * tile_stride  (1 for the full scan)
-    const void* qpad;     // [64, DIM] storage dtype
-    int q_count;          // real queries in the tile (<= 64)
-    const float* thr;     // [64] FILTER: keep score >= thr[q]
-    int2* lists;          // FILTER: [grid*256][cap] (score bits, local row)
-    int* counts;          // FILTER: [grid*256] candidates seen by each lane (may exceed cap)
+    const void* qpad;     // [64*NQ, DIM] storage dtype
+    int q_count;          // real queries in the tile (<= 64*NQ)
+    const float* thr;     // [64*NQ] FILTER: keep score >= thr[q]
+    int2* lists;          // FILTER: [grid*NQ*256][cap] (score bits, local row)
+    int* counts;          // FILTER: [grid*NQ*256] candidates seen by each lane (may exceed cap)
     int cap;
-    float* gmax;          // GROUPMAX: [grid*256] running max of each lane
+    float* gmax;          // GROUPMAX: [grid*NQ*256] running max of each lane
 };
 
 // LDS image of a stage (16 rows).  Two layouts are built; both are bank-conflict free for the
@@ -137,11 +161,137 @@ template <int AUX> __device__ __forceinline__ void glds16(const void* gsrc, void
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 
+// LDS-DMA with a scalar base and a 32-bit per-lane offset (no vector address arithmetic at all).
+// hipcc does not select this addressing form for the builtin, hence inline asm.  M0 (the LDS
+// destination) is compiler-reserved: it is saved, written and restored inside the one statement
+// that uses it.  hipcc neither counts this load nor pads its hazards: the opening s_nop 4 covers a
+// base that a vector instruction produced, s_nop 0 the M0 write, and the caller waits with vmcnt.
+template <int AUX>
+__device__ __forceinline__ void glds16_saddr(const void* base, uint32_t lane_off, uint32_t lds_dst) {
+    static_assert(AUX == 0 || AUX == 2, "asm DMA path knows the default and the nt policy");
+    uint32_t keep;
+    if constexpr (AUX == 2)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(base) : "memory");
+    else
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(base) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX>
+
+// ---- multi-group compute in inline asm (NQ >= 2) ----------------------------------------------
+// With 2..4 column groups the query operand (NQ*KSTEPS fragments of 4 registers) no longer fits the
+// 256 architectural VGPRs beside the row fragments.  hipcc then parks fragments in AGPRs and copies
+// each one back with four v_accvgpr_read before its MFMA, which doubles the issue cost.  MFMA can
+// read its B operand straight from an AGPR, so this path says so explicitly: fragments with index
+// j*KSTEPS+s >= VB are bound to AGPRs ("a"), the rest to VGPRs.  LDS reads are inline asm too, so
+// the next chunk of row fragments is requested before the MFMAs of the current chunk and waited for
+// with a counted lgkmcnt.
+template <int OFF> __device__ __forceinline__ void lds_read128_asm(half8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_read128_asm(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+// request the CH row fragments of chunk C (k-steps C*CH .. C*CH+CH-1) into af[0..CH)
+template <int C, int CH, int I, typename V>
+__device__ __forceinline__ void mg_load_chunk(V* af, const uint32_t (&base)[4]) {
+    if constexpr (I < CH) {
+        constexpr int s = C * CH + I;
+        lds_read128_asm<(s >> 2) * 256>(af[I], base[s & 3]);
+        mg_load_chunk<C, CH, I + 1, V>(af, base);
+    }
+}
+
+// wait until all but the N youngest LDS reads are back; naming every fragment as a read-write
+// operand keeps the MFMAs that consume them below this statement
+template <int N, int CH, int I, typename V>
+__device__ __forceinline__ void mg_wait_chunk(V* af) {
+    if constexpr (I < CH) {
+        if constexpr (I == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[0]) : "n"(N));
+        else asm volatile("" : "+v"(af[I]));
+        mg_wait_chunk<N, CH, I + 1, V>(af);
+    }
+}
+
+// MFMAs of k-step s = C*CH+I for the NQ column groups
+template <typename T, int NQ, int KSTEPS, int VB, int S, int J, typename V>
+__device__ __forceinline__ void mg_mfma_groups(f32x4* acc, const V& a, const V (*bq)[KSTEPS]) {
+    if constexpr (J < NQ) {
+        Elem<T>::template mfma_asm<(J * KSTEPS + S >= VB), S == 0>(acc[J], a, bq[J][S]);
+        mg_mfma_groups<T, NQ, KSTEPS, VB, S, J + 1, V>(acc, a, bq);
+    }
+}
+template <typename T, int NQ, int KSTEPS, int VB, int C, int CH, int I, typename V>
+__device__ __forceinline__ void mg_mfma_chunk(f32x4* acc, const V* af, const V (*bq)[KSTEPS]) {
+    if constexpr (I < CH) {
+        mg_mfma_groups<T, NQ, KSTEPS, VB, C * CH + I, 0, V>(acc, af[I], bq);
+        mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, I + 1, V>(acc, af, bq);
+    }
+}
+template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int C, typename V>
+__device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq)[KSTEPS],
+                                           const uint32_t (&base)[4]) {
+    if constexpr (C < NCH) {
+        if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
+        if constexpr (C + 1 < NCH) {
+            mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
+            mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
+        } else {
+            mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
+        }
+        mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
+        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, C + 1, V>(acc, af, bq, base);
+    }
+}
+// MFMA results must not be read by ordinary VALU code before the pipeline has written them:
+// hipcc pads nothing after inline asm
+template <int NQ, int J>
+__device__ __forceinline__ void mg_settle(f32x4* acc) {
+    if constexpr (J < NQ) {
+        if constexpr (J == 0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
+        else asm volatile("" : "+v"(acc[J]));
+        mg_settle<NQ, J + 1>(acc);
+    }
+}
+
+// Load the query operand.  Fragment f = j*KSTEPS + s goes to a VGPR tuple (ordinary load) or, on the
+// asm path for f >= VB, straight into an AGPR tuple (global_load can target AGPRs; an ordinary load
+// followed by a copy would be re-materialised by hipcc inside the loop).
+template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int LAYOUT, int F, typename V>
+__device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, int g) {
+    if constexpr (F < NQ * KSTEPS) {
+        constexpr int j = F / KSTEPS, s = F % KSTEPS;
+        const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
+        const T* src = qrow0 + (size_t)j * QGROUP * (KSTEPS * 32) + chunk * 8;
+        if constexpr (ASM_PATH && F >= VB) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[j][s]) : "v"(src) : "memory");
+        } else {
+            bq[j][s] = *(const V*)src;
+        }
+        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, F + 1, V>(bq, qrow0, g);
+    }
+}
+template <int NQ, int KSTEPS, int VB, bool ASM_PATH, int F, typename V>
+__device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
+    if constexpr (F < NQ * KSTEPS) {
+        constexpr int j = F / KSTEPS, s = F % KSTEPS;
+        if constexpr (ASM_PATH && F >= VB) asm volatile("" : "+a"(bq[j][s]));
+        else asm volatile("" ::"v"(bq[j][s]));
+        settle_queries<NQ, KSTEPS, VB, ASM_PATH, F + 1, V>(bq);
+    }
+}
+
+// Query q of the pass lives in column group j = q / 64, wave w = (q % 64) / 16, MFMA column r = q % 16.
+// List / counter / maximum of (workgroup b, group j, thread tid): index (b*NQ + j)*256 + tid.
+template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
     constexpr int KSTEPS = DIM / 32;       // MFMA 16x16x32 k-steps per row
@@ -160,30 +310,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15;  // MFMA row (row operand) / column (query operand) of this lane
     const int g = lane >> 4;  // MFMA k-group of this lane
-    const bool wave_active = (w * 16) < a.q_count;
+    const bool wave_active = (w * 16) < a.q_count;   // group 0 of this wave has a real query
+    // row-operand fragments are read in NCH chunks when the query operand leaves too few registers
+    constexpr int NCH = (KSTEPS >= 24) ? ((NQ >= 4) ? 6 : 4) : 1;
+    constexpr int CH = KSTEPS / NCH;
+    static_assert(KSTEPS % NCH == 0, "k-steps must split evenly into chunks");
+    // query fragments j*KSTEPS+s < VB live in VGPRs, the others in AGPRs (asm path, NQ >= 2)
+    constexpr int VB = (NQ <= 3) ? KSTEPS : KSTEPS + (KSTEPS * 3) / 8;
+    static_assert((NQ * KSTEPS - VB) * 4 <= 252 || NQ == 1, "query operand does not fit the AGPR file");
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     const T* __restrict__ rows = (const T*)a.rows;
     const long long n_rows = a.n_rows;
     const long long last_row = n_rows - 1;
 
     // ---- query operand: KSTEPS fragments of 8 elements, resident in registers for the whole launch
-    V bq[KSTEPS];
-    {
-        const T* qrow = (const T*)a.qpad + (size_t)(w * 16 + r) * DIM;
+    V bq[NQ][KSTEPS];
+    float thr[NQ];
+    constexpr bool ASM_PATH = (NQ >= 2 && LAYOUT == 1);
+    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
-            bq[s] = *(const V*)(qrow + chunk * 8);
-        }
-    }
-    float thr = 0.0f;
-    if (MODE == MODE_FILTER) thr = a.thr[w * 16 + r];
-    // drain the ordinary loads before any LDS-DMA is in flight, so that hipcc never has a reason to
-    // put a vmcnt(0) inside the streaming loop
+    for (int j = 0; j < NQ; ++j) thr[j] = (MODE == MODE_FILTER) ? a.thr[j * QGROUP + w * 16 + r] : 0.0f;
+    // drain these loads before any LDS-DMA is in flight, so that hipcc never has a reason to put a
+    // vmcnt(0) inside the streaming loop (the asm loads into AGPRs are not counted by hipcc at all)
     wait_vmcnt<0>();
+    settle_queries<NQ, KSTEPS, VB, ASM_PATH, 0>(bq);
 #pragma unroll
-    for (int i = 0; i < KSTEPS; ++i) asm volatile("" : "+v"(bq[i]));
-    asm volatile("" : "+v"(thr));
+    for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
 
     // ---- per-lane constants of the LDS image
     // LAYOUT 0, DMA side: lane i of piece (j, half) fetches row 8*half + (i>>3), chunk 8j + ((i&7) ^ ((i>>3)>>1))
@@ -208,11 +361,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     const long long n_it = (b < n_work) ? (n_work - b + grid - 1) / grid : 0;
     const long long last_work = n_work - 1;
 
+    // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
+    // (LAYOUT 1): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
+    uint32_t lane_off[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int pos = (w * PPW + pp) * 64 + lane;
+        const int trow = pos / CPR;
+        lane_off[pp] = (uint32_t)(trow * (DIM * 2) + (((pos - trow * CPR) ^ (trow & 15)) * 16));
+    }
+
     auto issue_stage = [&](long long it, int slot) {
         long long wk = b + it * grid;
         if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
         const long long row0 = wk * stride * TILE_ROWS;
         char* slot_base = smem + slot * STAGE_BYTES;
+        if (LAYOUT == 1 && row0 + TILE_ROWS <= n_rows) {
+            // whole tile in range (all but the last tile): uniform base + per-lane constant
+            const char* tile = (const char*)rows + row0 * (DIM * 2);
+            const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
+#pragma unroll
+            for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
+            return;
+        }
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
             const int p = w * PPW + pp;
@@ -227,17 +398,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 const int trow = pos / CPR;            // row of the tile the slot belongs to
                 const int chunk = (pos - trow * CPR) ^ (trow & 15);
                 long long row = row0 + trow;
-                if (row > last_row) row = last_row;
+                if (row > last_row) row = last_row;    // short last tile: re-read the last row
                 src = rows + row * DIM + chunk * 8;
             }
             glds16<AUX>(src, slot_base + p * 1024);
         }
     };
 
-    int cnt = 0;
-    float gm = -INFINITY;
-    int2* my_list = nullptr;
-    if (MODE == MODE_FILTER) my_list = a.lists + ((size_t)b * SCAN_THREADS + tid) * (size_t)a.cap;
+    int cnt[NQ];
+    float gm[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { cnt[j] = 0; gm[j] = -INFINITY; }
+    // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
+    int2* const my_list = (MODE == MODE_FILTER)
+        ? a.lists + ((size_t)b * NQ * SCAN_THREADS + tid) * (size_t)a.cap : nullptr;
+    const size_t list_stride = (size_t)SCAN_THREADS * (size_t)a.cap;  // between column groups
 
     if (n_it > 0) {
         // prologue: NSTAGE-1 stages in flight
@@ -256,41 +431,60 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
 
             if (wave_active) {
                 const char* sb = smem + slot * STAGE_BYTES;
-                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                // all row fragments of the stage are requested before the first MFMA, so the LDS
-                // latency is paid once per stage and not once per k-step
-                V af[KSTEPS];
+                f32x4 acc[NQ];
+                if constexpr (NQ == 1 || LAYOUT == 0) {
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    if (LAYOUT == 0) af[s] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
-                    else af[s] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
+                    for (int j = 0; j < NQ; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    // the row fragments are all requested before the first MFMA, so the LDS latency is
+                    // paid once per stage and not once per k-step
+                    V af[KSTEPS];
+#pragma unroll
+                    for (int s = 0; s < KSTEPS; ++s) {
+                        if (LAYOUT == 0) af[s] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
+                        else af[s] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) acc[j] = Elem<T>::mfma(af[s], bq[j][s], acc[j]);
+                    }
+                    // pin the order in the emitted code: the ds_read_b128s, then the MFMAs behind counted
+                    // lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA to save VGPRs)
+                    __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS * NQ, 0);
+                } else {
+                    // chunks of CH k-steps, row fragments double-buffered in registers
+                    V af[2][CH];
+                    uint32_t base[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) base[m] = lds_base + (uint32_t)(slot * STAGE_BYTES + rd_off[m]);
+                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, 0, V>(acc, af, bq, base);
+                    mg_settle<NQ, 0>(acc);
                 }
-#pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) acc = Elem<T>::mfma(af[s], bq[s], acc);
-                // pin the order in the emitted code: all ds_read_b128, then the MFMAs behind counted
-                // lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA to save VGPRs)
-                __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
-                // acc[i] = score(row = tile*16 + g*4 + i, query = w*16 + r)
+                // acc[j][i] = score(row = tile*16 + g*4 + i, query = j*64 + w*16 + r)
                 const long long row_base = (b + it * grid) * stride * TILE_ROWS + g * 4;
-                if (MODE == MODE_FILTER) {
-                    const float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-                    if (__builtin_amdgcn_ballot_w64(m >= thr) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    if (MODE == MODE_FILTER) {
+                        const float m = fmaxf(fmaxf(acc[j][0], acc[j][1]), fmaxf(acc[j][2], acc[j][3]));
+                        if (__builtin_amdgcn_ballot_w64(m >= thr[j]) != 0ull) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const long long row = row_base + i;
+                                if (acc[j][i] >= thr[j] && row < n_rows) {
+                                    if (cnt[j] < a.cap)
+                                        my_list[j * list_stride + cnt[j]] =
+                                            make_int2(__float_as_int(acc[j][i]), (int)row);
+                                    ++cnt[j];
+                                }
+                            }
+                        }
+                    } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const long long row = row_base + i;
-                            if (acc[i] >= thr && row < n_rows) {
-                                if (cnt < a.cap)
-                                    my_list[cnt] = make_int2(__float_as_int(acc[i]), (int)row);
-                                ++cnt;
-                            }
+                            if (row < n_rows) gm[j] = fmaxf(gm[j], acc[j][i]);
                         }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const long long row = row_base + i;
-                        if (row < n_rows) gm = fmaxf(gm, acc[i]);
                     }
                 }
             }
@@ -299,8 +493,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
         wait_vmcnt<0>();
     }
-    if (MODE == MODE_FILTER) a.counts[(size_t)b * SCAN_THREADS + tid] = cnt;
-    else a.gmax[(size_t)b * SCAN_THREADS + tid] = gm;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const size_t o = ((size_t)b * NQ + j) * SCAN_THREADS + tid;
+        if (MODE == MODE_FILTER) a.counts[o] = cnt[j];
+        else a.gmax[o] = gm[j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,7 +622,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
 constexpr int KTH_SORT_MAX = 2048;
 
 __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
-                                                          int scan_grid, int k, int q_count,
+                                                          int scan_grid, int nq, int k, int q_count,
                                                           float* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* vals = (uint32_t*)smem;
@@ -443,7 +641,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
     }
     for (int i = tid; i < G; i += SEL_THREADS) {
         const int bb = i >> 2, gg = i & 3;
-        vals[i] = f2ord(gmax[(size_t)bb * SCAN_THREADS + (q >> 4) * 64 + gg * 16 + (q & 15)]);
+        vals[i] = f2ord(gmax[((size_t)bb * nq + (q >> 6)) * SCAN_THREADS + ((q & 63) >> 4) * 64 + gg * 16 + (q & 15)]);
     }
     uint32_t kth;
     if (G <= KTH_SORT_MAX) {
@@ -460,9 +658,9 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
 }
 
 // thresholds when pass 0 is skipped (small shards): keep everything for real queries
-__global__ void fill_thr_kernel(float* thr, int q_count) {
+__global__ void fill_thr_kernel(float* thr, int q_count, int q_tile) {
     const int q = threadIdx.x;
-    if (q < QTILE) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
+    if (q < q_tile) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,8 +776,9 @@ struct SelectArgs {
     const int* counts;
     int cap;
     int scan_grid;          // blocks of the FILTER scan (<= 1024)
+    int nq;                 // column groups of the FILTER scan
     const int32_t* ids;     // [n_rows] passage id of each local row
-    u64* keys_ws;           // [64][keys_stride] global key scratch for M > SORT_MAX
+    u64* keys_ws;           // [q_tile][keys_stride] global key scratch for M > SORT_MAX
     long long keys_stride;
     int k;
     void* out_scores;
@@ -601,7 +800,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     const int tid = threadIdx.x;
     const int L = a.scan_grid * 4;  // candidate lists of this query
     auto list_of = [&](int li) -> size_t {
-        return (size_t)(li >> 2) * SCAN_THREADS + (q >> 4) * 64 + (li & 3) * 16 + (q & 15);
+        return ((size_t)(li >> 2) * a.nq + (q >> 6)) * SCAN_THREADS + ((q & 63) >> 4) * 64 + (li & 3) * 16 + (q & 15);
     };
     // ---- exclusive offsets of the lists: thread t owns lists [t*per, t*per+per)
     const int per = (L + SEL_THREADS - 1) / SEL_THREADS;  // <= 4

@@ -120,6 +120,10 @@ def _random_case(n, q, dim, seed, scale=0.05):
     (50000, 65, 32, 768),    # two query tiles (64 + 1)
     (50000, 130, 100, 768),  # three query tiles, eval's k
     (30000, 16, 100, 1024),  # BERT-large width
+    (30000, 150, 20, 1024),  # BERT-large width, two column groups + a second pass
+    (40000, 256, 32, 768),   # one full 256-query pass (4 column groups)
+    (40000, 700, 10, 768),   # 256 + 256 + 188: passes with 4 and 3 column groups
+    (3000, 200, 50, 128),    # small-N path (no pass 0) with 4 column groups
     (30000, 16, 10, 128),
     (100000, 8, 1000, 768),  # large k: radix-select path in global memory
     (9000, 4, 2048, 768),    # k == ARTMIPS_MAX_K on a shard above SORT_MAX rows

@@ -20,6 +20,7 @@ p.add_argument("--variants", default="0,1,2,3")
 p.add_argument("--rounds", type=int, default=6)
 p.add_argument("--queries", type=int, default=64)
 p.add_argument("--topk", type=int, default=32)
+p.add_argument("--nq-sweep", action="store_true", help="variants are values of ARTMIPS_MAX_NQ (1..4)")
 args = p.parse_args()
 
 eng = MipsEngine(768, torch.float16, [0])
@@ -35,6 +36,9 @@ for rnd in range(args.rounds + 1):
     for v in variants:
         os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
         os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
+        if args.nq_sweep:
+            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
+            os.environ["ARTMIPS_MAX_NQ"] = v
         s, i = eng.search(q, args.topk, score_dtype=torch.float32)
         info = eng.info()
         if rnd > 0:
@@ -52,5 +56,8 @@ for v in variants:
     t = sorted(times[v])
     tt = sorted(totals[v])
     med, mn = t[len(t) // 2], t[0]
-    print("variant %s: scan median %.3f ms (%.0f GB/s)  min %.3f ms (%.0f GB/s)  pipeline median %.3f ms"
-          % (v, med, bytes_ / med / 1e6, mn, bytes_ / mn / 1e6, tt[len(tt) // 2]), flush=True)
+    tot = tt[len(tt) // 2]
+    print("variant %s: scan median %.3f ms (%.0f GB/s per sweep-byte)  min %.3f ms  pipeline median %.3f ms  "
+          "-> %.0f queries/s, %.1f TFLOP/s"
+          % (v, med, bytes_ * info["last_scan_launches"] / med / 1e6, mn, tot, args.queries / tot * 1e3,
+             2.0 * args.queries * args.rows * 768 / tot / 1e9), flush=True)
