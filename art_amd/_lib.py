@@ -47,6 +47,8 @@ class ArtmipsInfo(ctypes.Structure):
         ("last_scan_launches", ctypes.c_int32),
         ("last_retries", ctypes.c_int32),
         ("last_candidates", ctypes.c_int64),
+        ("last_host_enqueue_us", ctypes.c_float),
+        ("last_host_sync_us", ctypes.c_float),
     ]
 
 

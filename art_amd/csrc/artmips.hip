@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -97,6 +99,9 @@ struct artmips {
     int last_scan_launches = 0, last_retries = 0;
     int64_t last_candidates = 0;
     int cap_boost = 1;  // sticky multiplier learnt from overflow retries
+    bool stats_pending = false;
+    double host_enqueue_us = 0, host_sync_us = 0;
+    int stats_slot = 0, stats_tiles = 0;
 };
 
 static size_t elem_size(int dtype) { return dtype == ARTMIPS_F32 ? 4 : 2; }
@@ -498,9 +503,9 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
 
 template <typename T>
 static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int dim, void* out,
-                        hipStream_t st) {
+                        int* status_to_clear, hipStream_t st) {
     hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(64 * (q_tile / QGROUP)), dim3(256), 0, st, q, q_dtype,
-                       q_count, q_tile, dim, (T*)out);
+                       q_count, q_tile, dim, (T*)out, status_to_clear);
 }
 
 // Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
@@ -509,8 +514,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
                         long long out_row0, hipStream_t st, int tile_index) {
     const Generation& gen = s.live;
     const int qt = p.nq * QGROUP;
-    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
-    else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+    int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;
+    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
+    else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
     HIP_TRY(hipGetLastError());
 
     ScanArgs a;
@@ -532,7 +538,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         if (rc) return rc;
         size_t kth_lds = 8;
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
-        hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(SEL_THREADS), kth_lds * 4, st,
+        const int kth_threads = (p.grid0 * 4 <= 4096) ? 256 : SEL_THREADS;
+        hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
                            (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p);
         HIP_TRY(hipGetLastError());
     } else {
@@ -569,7 +576,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     sa.out_row0 = out_row0;
     sa.status = (int*)s.status.p;
     sa.cand_total = (unsigned long long*)((int*)s.status.p + 2);
-    hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(SEL_THREADS), 0, st, sa);
+    // few candidates per query (small k): 4 waves sort faster than 16 (cheaper barriers)
+    const int sel_threads = (k <= 128 && p.pass0) ? 256 : SEL_THREADS;
+    hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(sel_threads), 0, st, sa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -592,6 +601,7 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
         int nq = (int)std::min<int64_t>((n_q + QGROUP - 1) / QGROUP, max_nq(h->dim));
         if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
         const int QT = nq * QGROUP;
+        const auto t_begin = std::chrono::steady_clock::now();
         Plan p = make_plan(s, gen.n_rows, k, h->cap_boost, nq);
         // workspace
         int rc = 0;
@@ -607,7 +617,6 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
         if (keys_per_q > (size_t)SORT_MAX) {
             if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
         }
-        HIP_TRY(hipMemsetAsync(s.status.p, 0, 64, st));
         if (record_stats) HIP_TRY(hipEventRecord(s.ev_t0, st));
         int n_tiles_q = 0;
         for (int64_t q0 = 0; q0 < n_q; q0 += QT, ++n_tiles_q) {
@@ -618,7 +627,11 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
         }
         if (record_stats) HIP_TRY(hipEventRecord(s.ev_t1, st));
         HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, st));
+        const auto t_enq = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(st));
+        const auto t_syn = std::chrono::steady_clock::now();
+        h->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - t_begin).count();
+        h->host_sync_us = std::chrono::duration<double, std::micro>(t_syn - t_enq).count();
         const int status = s.status_host[0];
         if (status & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
         if (status & 1) {
@@ -630,16 +643,9 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
             continue;
         }
         if (record_stats) {
-            float ms = 0, total = 0;
-            for (int t = 0; t < n_tiles_q; ++t) {
-                float x = 0;
-                HIP_TRY(hipEventElapsedTime(&x, s.ev_scan[2 * t], s.ev_scan[2 * t + 1]));
-                ms += x;
-            }
-            HIP_TRY(hipEventElapsedTime(&total, s.ev_t0, s.ev_t1));
-            h->last_scan_ms = ms;
-            h->last_total_ms = total;
-            h->last_scan_launches = n_tiles_q;
+            h->stats_slot = slot;
+            h->stats_tiles = n_tiles_q;
+            h->stats_pending = true;  // event times are read when artmips_info asks for them
             h->last_retries = retries;
             unsigned long long c = 0;
             memcpy(&c, s.status_host + 2, 8);
@@ -674,6 +680,15 @@ extern "C" int artmips_search_local(artmips_t* h, int slot, const void* q_dev, i
                         (hipStream_t)stream, true);
 }
 
+// Scratch of the handle-less artmips_merge: one (status, keys) pair per device, kept for the life
+// of the process.  A buffer only ever grows, and growing waits for the device first, so a merge
+// still in flight on some stream never loses its scratch.
+struct MergeScratch {
+    DevBuf keys, status;
+};
+static MergeScratch g_merge_scratch[ARTMIPS_MAX_DEVICES * 4];
+static std::mutex g_merge_mutex;
+
 static int run_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
                      int k, void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
                      DevBuf* keys, DevBuf* status_buf) {
@@ -689,26 +704,25 @@ static int run_merge(int device, const float* scores, const int32_t* ids, int n_
     m.score_dtype = score_dtype;
     m.out_ids = out_ids;
     const long long total = (long long)n_lists * k;
-    DevBuf local_keys, local_status;
-    DevBuf* kb = keys ? keys : &local_keys;
-    DevBuf* sb = status_buf ? status_buf : &local_status;
     int rc = 0;
-    if ((rc = ensure(*sb, 64))) return rc;
+    if (status_buf->bytes < 64) {
+        if ((rc = ensure(*status_buf, 64))) return rc;
+        HIP_TRY(hipMemset(status_buf->p, 0, 64));
+    }
     if (total > SORT_MAX) {
-        if ((rc = ensure(*kb, (size_t)total * 8 * (size_t)n_q))) { release(local_status); return rc; }
-        m.keys_ws = (u64*)kb->p;
+        const size_t need = (size_t)total * 8 * (size_t)n_q;
+        if (keys->bytes < need) {
+            HIP_TRY(hipDeviceSynchronize());
+            if ((rc = ensure(*keys, need))) return rc;
+        }
+        m.keys_ws = (u64*)keys->p;
         m.keys_stride = total;
     }
-    m.status = (int*)sb->p;
-    hipError_t e = hipMemsetAsync(sb->p, 0, 64, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n_q), dim3(SEL_THREADS), 0, st, m);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    release(local_keys);
-    release(local_status);
-    if (e != hipSuccess) return fail(ARTMIPS_ERR_HIP, "merge failed: %s", hipGetErrorString(e));
+    // the kernel can only raise status bit 1 if keys_stride were too small, which the sizing above
+    // rules out; the merge is therefore left asynchronous on `st`
+    m.status = (int*)status_buf->p;
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n_q), dim3(SEL_THREADS), 0, st, m);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -719,8 +733,11 @@ extern "C" int artmips_merge(int device, const float* scores, const int32_t* ids
     if (n_lists < 1 || n_q < 1 || k < 1) return fail(ARTMIPS_ERR_ARG, "n_lists, n_q and k must be >= 1");
     if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
     if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
+    if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
+    std::lock_guard<std::mutex> lock(g_merge_mutex);
+    MergeScratch& ms = g_merge_scratch[device];
     return run_merge(device, scores, ids, n_lists, n_q, k, out_scores, score_dtype, out_ids,
-                     (hipStream_t)stream, nullptr, nullptr);
+                     (hipStream_t)stream, &ms.keys, &ms.status);
 }
 
 extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
@@ -787,12 +804,31 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
         DeviceGuard g(s0.dev);
         for (int i : used) HIP_TRY(hipStreamWaitEvent(st, h->sh[i].ev_done, 0));
     }
-    return run_merge(s0.dev, (const float*)h->g_scores.p, (const int32_t*)h->g_ids.p, active, n_q, k,
-                     out_scores, score_dtype, out_ids, st, &h->m_keys, &h->m_status);
+    rc = run_merge(s0.dev, (const float*)h->g_scores.p, (const int32_t*)h->g_ids.p, active, n_q, k,
+                   out_scores, score_dtype, out_ids, st, &h->m_keys, &h->m_status);
+    if (rc) return rc;
+    DeviceGuard g(s0.dev);
+    HIP_TRY(hipStreamSynchronize(st));  // the search entry points return with the stream drained
+    return 0;
 }
 
 extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
     if (!h || !out) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (h->stats_pending) {
+        Shard& s = h->sh[h->stats_slot];
+        DeviceGuard g(s.dev);
+        float ms = 0, total = 0;
+        for (int t = 0; t < h->stats_tiles; ++t) {
+            float x = 0;
+            HIP_TRY(hipEventElapsedTime(&x, s.ev_scan[2 * t], s.ev_scan[2 * t + 1]));
+            ms += x;
+        }
+        HIP_TRY(hipEventElapsedTime(&total, s.ev_t0, s.ev_t1));
+        h->last_scan_ms = ms;
+        h->last_total_ms = total;
+        h->last_scan_launches = h->stats_tiles;
+        h->stats_pending = false;
+    }
     memset(out, 0, sizeof(*out));
     out->n_dev = h->n_dev;
     out->dim = h->dim;
@@ -813,5 +849,7 @@ extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
     out->last_scan_launches = h->last_scan_launches;
     out->last_retries = h->last_retries;
     out->last_candidates = h->last_candidates;
+    out->last_host_enqueue_us = (float)h->host_enqueue_us;
+    out->last_host_sync_us = (float)h->host_sync_us;
     return 0;
 }

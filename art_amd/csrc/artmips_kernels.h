@@ -113,7 +113,9 @@ __device__ __forceinline__ void store_score(void* out, int dtype, int64_t idx, f
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_queries_kernel(const void* __restrict__ q, int q_dtype, int q_count, int q_tile,
-                                    int dim, T* __restrict__ out) {
+                                    int dim, T* __restrict__ out, int* __restrict__ status_to_clear) {
+    // first tile of a search: also clear the 16 status words the later kernels raise
+    if (status_to_clear != nullptr && blockIdx.x == 0 && threadIdx.x < 16) status_to_clear[threadIdx.x] = 0;
     const int total = q_tile * dim;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / dim;
@@ -139,9 +141,9 @@ struct ScanArgs {
     int q_count;          // real queries in the tile (<= 64*NQ)
     const float* thr;     // [64*NQ] FILTER: keep score >= thr[q]
     int2* lists;          // FILTER: [grid*NQ*256][cap] (score bits, local row)
-    int* counts;          // FILTER: [grid*NQ*256] candidates seen by each lane (may exceed cap)
+    int* counts;          // FILTER: [64*NQ][grid*4] candidates seen by each lane (may exceed cap)
     int cap;
-    float* gmax;          // GROUPMAX: [grid*NQ*256] running max of each lane
+    float* gmax;          // GROUPMAX: [64*NQ][grid*4] running max of each lane
 };
 
 // LDS image of a stage (16 rows).  Two layouts are built; both are bank-conflict free for the
@@ -493,9 +495,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
         wait_vmcnt<0>();
     }
+    // counters / maxima are stored query-major ([query][workgroup*4 + lane group]) so that the
+    // selection kernels read the L values of a query as one contiguous run
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const size_t o = ((size_t)b * NQ + j) * SCAN_THREADS + tid;
+        const size_t o = (size_t)(j * QGROUP + w * 16 + r) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
         if (MODE == MODE_FILTER) a.counts[o] = cnt[j];
         else a.gmax[o] = gm[j];
     }
@@ -619,8 +623,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
 // score over the whole shard is >= tau: dropping every score < tau loses no top-k member.
 // One block per query slot (64 blocks); dynamic LDS = next_pow2(n_groups) * 4 bytes.
 // ---------------------------------------------------------------------------------------------
-constexpr int KTH_SORT_MAX = 2048;
-
 __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
                                                           int scan_grid, int nq, int k, int q_count,
                                                           float* __restrict__ thr) {
@@ -639,21 +641,9 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
         if (tid == 0) thr[q] = -INFINITY;
         return;
     }
-    for (int i = tid; i < G; i += SEL_THREADS) {
-        const int bb = i >> 2, gg = i & 3;
-        vals[i] = f2ord(gmax[((size_t)bb * nq + (q >> 6)) * SCAN_THREADS + ((q & 63) >> 4) * 64 + gg * 16 + (q & 15)]);
-    }
-    uint32_t kth;
-    if (G <= KTH_SORT_MAX) {
-        const int P = next_pow2(G < 2 ? 2 : G);
-        for (int i = G + tid; i < P; i += SEL_THREADS) vals[i] = 0u;
-        __syncthreads();
-        bitonic_sort_desc<uint32_t>(vals, P);
-        kth = vals[k - 1];
-    } else {
-        __syncthreads();
-        kth = radix_kth<uint32_t>(vals, G, k, hist, ctl);
-    }
+    for (int i = tid; i < G; i += blockDim.x) vals[i] = f2ord(gmax[(size_t)q * G + i]);
+    __syncthreads();
+    const uint32_t kth = radix_kth<uint32_t>(vals, G, k, hist, ctl);
     if (tid == 0) thr[q] = ord2f(kth);
 }
 
@@ -693,38 +683,49 @@ __device__ __forceinline__ void write_topk(const u64* sorted, int n_sorted, cons
     }
 }
 
-// The M keys are in keys[0..M): in LDS (== sc.skeys) when in_lds, else in global memory.
+// A "pre-key" is ordered(score) << 32 | local row: enough to filter on the score.  Turning it into
+// the final key needs the passage id of the row (a dependent HBM load), so that is done only for
+// the keys that survive the score filter.  row_ids == nullptr means the keys are final already.
+__device__ __forceinline__ u64 finish_key(u64 pre, const int32_t* row_ids) {
+    if (row_ids == nullptr) return pre;
+    const int32_t id = row_ids[(uint32_t)pre];
+    return (pre & 0xffffffff00000000ull) | (u64)(uint32_t)(~(((uint32_t)id) ^ 0x80000000u));
+}
+
+// The M (pre-)keys are in keys[0..M): in LDS (== sc.skeys) when in_lds, else in global memory.
 // Writes the k best in order; output slots beyond M get (-inf, INT32_MAX).
 //
 // Three routes, all exact:
-//   two-level  (small k, many keys): sort a sample of the first ns keys, take its k-th as a second
-//              lower bound, keep the few keys above it, sort those;
+//   two-level  (small k, many keys): radix-select the k-th largest SCORE of the first ns keys (a
+//              second lower bound of the k-th best score), keep the few keys at or above it,
+//              finish and sort those;
 //   full sort  (M <= SORT_MAX keys in LDS);
 //   radix      (keys in global memory): radix-select the k-th key, gather the k keys above it, sort.
-__device__ void topk_finish(const u64* keys, int M, bool in_lds, const TopkScratch& sc, const TopkOut& o) {
+__device__ void topk_finish(u64* keys, int M, bool in_lds, const int32_t* row_ids,
+                            const TopkScratch& sc, const TopkOut& o) {
     const int tid = threadIdx.x;
     const int k = o.k;
     if (M <= 0) { write_topk(sc.sub, 0, o); return; }
     // ---- two-level route
     int ns = next_pow2(4 * k);
     if (ns < 512) ns = 512;
-    if (ns <= SUB_MAX && M >= 4 * ns) {
-        for (int i = tid; i < ns; i += blockDim.x) sc.sub[i] = keys[i];
+    if (ns <= SUB_MAX && M >= 2 * ns) {
+        uint32_t* sample = (uint32_t*)sc.sub;
+        for (int i = tid; i < ns; i += blockDim.x) sample[i] = (uint32_t)(keys[i] >> 32);
         __syncthreads();
-        bitonic_sort_desc<u64>(sc.sub, ns);
-        const u64 bound = sc.sub[k - 1];   // k sampled keys are >= bound, so is the true k-th key
-        __syncthreads();
-        if (tid == 0) sc.ctl[0] = 0;
+        // k sampled rows score >= bound, so the true k-th best score does too
+        const uint32_t bound = radix_kth<uint32_t>(sample, ns, k, sc.hist, sc.ctl);
+        if (tid == 0) sc.ctl[2] = 0;
         __syncthreads();
         for (int i = tid; i < M; i += blockDim.x) {
             const u64 key = keys[i];
-            if (key >= bound) {
-                const int pos = atomicAdd(&sc.ctl[0], 1);
-                if (pos < SUB_MAX) sc.sub[pos] = key;
+            if ((uint32_t)(key >> 32) >= bound) {
+                const int pos = atomicAdd(&sc.ctl[2], 1);
+                if (pos < SUB_MAX) sc.sub[pos] = finish_key(key, row_ids);
             }
         }
         __syncthreads();
-        const int got = sc.ctl[0];
+        const int got = sc.ctl[2];
         __syncthreads();
         if (got <= SUB_MAX) {
             const int P = next_pow2(got < 2 ? 2 : got);
@@ -734,7 +735,11 @@ __device__ void topk_finish(const u64* keys, int M, bool in_lds, const TopkScrat
             write_topk(sc.sub, got, o);
             return;
         }
-        // too many survivors (skewed sample): fall through to the unconditional routes
+        // too many survivors (skewed sample or massive score ties): unconditional routes below
+    }
+    if (row_ids != nullptr) {
+        for (int i = tid; i < M; i += blockDim.x) keys[i] = finish_key(keys[i], row_ids);
+        __syncthreads();
     }
     if (in_lds) {
         const int P = next_pow2(M < 2 ? 2 : M);
@@ -803,25 +808,27 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         return ((size_t)(li >> 2) * a.nq + (q >> 6)) * SCAN_THREADS + ((q & 63) >> 4) * 64 + (li & 3) * 16 + (q & 15);
     };
     // ---- exclusive offsets of the lists: thread t owns lists [t*per, t*per+per)
-    const int per = (L + SEL_THREADS - 1) / SEL_THREADS;  // <= 4
-    int c[4] = {0, 0, 0, 0};
+    const int nt = blockDim.x;
+    const int per = (L + nt - 1) / nt;
     int mine = 0, ovf = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < per; ++i) {
         const int li = tid * per + i;
-        if (i < per && li < L) {
-            int v = a.counts[list_of(li)];
+        if (li < L) {
+            int v = a.counts[(size_t)q * L + li];
             if (v > a.cap) { ovf = 1; v = a.cap; }
-            c[i] = v;
             mine += v;
         }
     }
     int M;
     int off = block_excl_scan(mine, wsum, &M);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < per; ++i) {
         const int li = tid * per + i;
-        if (i < per && li < L) { loff[li] = off; off += c[i]; }
+        if (li < L) {
+            int v = a.counts[(size_t)q * L + li];
+            if (v > a.cap) v = a.cap;
+            loff[li] = off;
+            off += v;
+        }
     }
     if (tid == 0) loff[L] = M;
     if (ovf) atomicOr(a.status, 1);
@@ -835,21 +842,31 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         return;
     }
     // ---- balanced gather: candidate e of the query lives in the list found by binary search over
-    // the offsets; every thread handles M/1024 candidates with independent loads
+    // the offsets; every thread handles M/nt candidates with independent loads.  The keys written
+    // here are pre-keys (score, row); passage ids are looked up only for the survivors.
     u64* dst = in_lds ? skeys : gk;
-    for (int e = tid; e < M; e += SEL_THREADS) {
-        int lo = 0, hi = L;  // invariant: loff[lo] <= e < loff[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (loff[mid] <= e) lo = mid; else hi = mid;
+    {
+        // thread t takes candidates [t*cpt, t*cpt+cpt): one binary search, then a linear walk
+        const int cpt = (M + nt - 1) / nt;
+        int e = tid * cpt;
+        const int e_end = (e + cpt < M) ? e + cpt : M;
+        if (e < e_end) {
+            int lo = 0, hi = L;  // invariant: loff[lo] <= e < loff[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (loff[mid] <= e) lo = mid; else hi = mid;
+            }
+            for (; e < e_end; ++e) {
+                while (loff[lo + 1] <= e) ++lo;
+                const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+                dst[e] = ((u64)f2ord(__int_as_float(ent.x)) << 32) | (u64)(uint32_t)ent.y;
+            }
         }
-        const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
-        dst[e] = make_key(__int_as_float(ent.x), a.ids[ent.y]);
     }
     __syncthreads();
     TopkScratch sc{skeys, sub, hist, ctl};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
-    topk_finish(dst, M, in_lds, sc, o);
+    topk_finish(dst, M, in_lds, a.ids, sc, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -888,7 +905,7 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     if (tid == 0) s_fill = 0;
     __syncthreads();
     u64* dst = in_lds ? skeys : gk;
-    for (int i = tid; i < total; i += SEL_THREADS) {
+    for (int i = tid; i < total; i += blockDim.x) {
         const int l = i / a.k, j = i - l * a.k;
         const size_t src = ((size_t)l * a.n_q + q) * a.k + j;
         const int32_t id = a.ids[src];
@@ -900,7 +917,7 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     const int M = s_fill;
     TopkScratch sc{skeys, sub, hist, ctl};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, q, a.k};
-    topk_finish(dst, M, in_lds, sc, o);
+    topk_finish(dst, M, in_lds, nullptr, sc, o);
 }
 
 }  // namespace artk

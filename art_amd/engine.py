@@ -202,6 +202,8 @@ class MipsEngine(object):
             "last_scan_launches": out.last_scan_launches,
             "last_retries": out.last_retries,
             "last_candidates": out.last_candidates,
+            "last_host_enqueue_us": out.last_host_enqueue_us,
+            "last_host_sync_us": out.last_host_sync_us,
         }
 
 

@@ -16,9 +16,10 @@
  *   - device pointers are raw HIP device addresses (torch: tensor.data_ptr()).
  *   - `stream` is a hipStream_t passed as void* (torch:
  *     torch.cuda.current_stream().cuda_stream); NULL is the default stream.
- *   - all device work is enqueued on / ordered against `stream`; search entry
+ *   - all device work is enqueued on / ordered against `stream`; the search entry
  *     points synchronise that stream before they return (they must read a
- *     device status word to guarantee exactness).
+ *     device status word to guarantee exactness);
+ *     artmips_merge does not.
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
  *   - passage ids are int32 (the reference returns int32: art_index.py:297).
  *   - top-k order: score descending, ties broken by LOWER passage id
@@ -71,6 +72,8 @@ typedef struct artmips_info {
     int32_t last_scan_launches;
     int32_t last_retries; /* candidate-list overflow retries taken by the last call      */
     int64_t last_candidates; /* candidates kept by the filter, summed over queries        */
+    float last_host_enqueue_us; /* host time to plan + enqueue the last search (slot 0)     */
+    float last_host_sync_us;    /* host time spent waiting for the stream afterwards        */
 } artmips_info_t;
 
 /* Replaces DistributedBruteForceIndex.__init__ (art_index.py:201-209): one handle
@@ -123,7 +126,8 @@ int artmips_search_local(artmips_t* h, int slot, const void* q_dev, int q_dtype,
                          int k, float* out_scores, int32_t* out_ids, void* stream);
 
 /* k-way merge of n_lists candidate lists, each [n_q, k] (fp32 score, int32 id),
- * laid out [n_lists, n_q, k] as an all-gather leaves them.  Runs on `device`.
+ * laid out [n_lists, n_q, k] as an all-gather leaves them.  Runs on `device`,
+ * asynchronously on `stream` (the only entry point that does not synchronise).
  * Replaces the gather of score slabs to GPU-0 and torch.topk over them
  * (art_index.py:283-294) with a merge over k*n_lists candidates per query. */
 int artmips_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,

@@ -36,8 +36,8 @@ def test_version_and_error_string_without_gpu():
 
 
 def test_info_struct_layout_matches_header():
-    # artmips_info_t: 4 x int32, int64, 16 x int64, 2 x int64, 2 x float, 2 x int32, int64
-    assert ctypes.sizeof(_lib.ArtmipsInfo) == 16 + 8 + 16 * 8 + 16 + 8 + 8 + 8
+    # artmips_info_t: 4 x int32, int64, 16 x int64, 2 x int64, 2 x float, 2 x int32, int64, 2 x float
+    assert ctypes.sizeof(_lib.ArtmipsInfo) == 16 + 8 + 16 * 8 + 16 + 8 + 8 + 8 + 8
 
 
 def test_no_oracle_or_cpu_fallback_in_product():
