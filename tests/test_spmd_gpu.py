@@ -1,0 +1,51 @@
+"""The SPMD path (one process per shard) end to end on the GPU box: two ranks share the one GPU,
+each owns half of the rows in its own MipsEngine, candidates travel through torch.distributed
+(gloo here: RCCL refuses two ranks on one device; the driver's multi-GPU bench uses "nccl"), and
+every rank merges on the device.  Compared with the golden fixture and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd.distributed import engine_spmd_search, shard_bounds
+        from art_amd.engine import MipsEngine
+        torch.cuda.set_device(0)
+        fx = np.load(os.path.join(GOLDEN, "fx_shard_edges.npz"))
+        rows = fx["rows_i8"].astype(np.float16)
+        lo, hi = shard_bounds(rows.shape[0], world)[rank]
+        eng = MipsEngine(768, torch.float16, [0])
+        eng.build(rows[lo:hi], fx["ids"][lo:hi])
+        q = torch.from_numpy(fx["queries_i8"].astype(np.float16)).cuda()
+        for k in (8, 32):
+            s, i = engine_spmd_search(eng, q, k, score_dtype=torch.float32)
+            torch.cuda.synchronize()
+            np.save(os.path.join(out_dir, "s%d_%d.npy" % (k, rank)), s.cpu().numpy())
+            np.save(os.path.join(out_dir, "i%d_%d.npy" % (k, rank)), i.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spmd_two_ranks_one_gpu(tmp_path, world):
+    assert torch.cuda.is_available()
+    port = 29600 + (os.getpid() % 300) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    fx = np.load(os.path.join(GOLDEN, "fx_shard_edges.npz"))
+    for k in (8, 32):
+        for r in range(world):
+            np.testing.assert_array_equal(np.load(tmp_path / ("i%d_%d.npy" % (k, r))), fx["ids_k%d" % k])
+            np.testing.assert_array_equal(np.load(tmp_path / ("s%d_%d.npy" % (k, r))), fx["scores_k%d" % k])
