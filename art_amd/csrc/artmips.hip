@@ -139,7 +139,7 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
-    const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * 2;
+    const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T);
     static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -211,13 +211,21 @@ static int launch_scan_dt(int dim, int nq, int mode, const ScanArgs& a, int grid
 static int launch_scan(int dtype, int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dtype == ARTMIPS_F16) return launch_scan_dt<_Float16>(dim, nq, mode, a, grid, st);
     if (dtype == ARTMIPS_BF16) return launch_scan_dt<__bf16>(dim, nq, mode, a, grid, st);
+    if (dtype == ARTMIPS_F32 && nq == 1) {
+        // fp32 rows: 48 KiB stages, exact-f32 MFMA (1/16 of the f16 rate): one column group only
+        if (dim == 768) return launch_scan_t<float, 768, 3, 1, 2, 1>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<float, 128, 8, 1, 2, 1>(mode, a, grid, st);
+    }
     return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for storage_dtype=%d", dtype);
 }
 
 // column groups per pass the kernels are built for at this width
-static int max_nq(int dim) { return dim == 1024 ? 2 : MAX_NQ; }
+static int max_nq(int dim, int dtype) { return dtype == ARTMIPS_F32 ? 1 : (dim == 1024 ? 2 : MAX_NQ); }
 
-static bool dim_supported(int dim) { return dim == 768 || dim == 1024 || dim == 128; }
+static bool dim_supported(int dim, int dtype) {
+    if (dtype == ARTMIPS_F32) return dim == 768 || dim == 128;
+    return dim == 768 || dim == 1024 || dim == 128;
+}
 
 // ---------------------------------------------------------------------------------------------
 // create / destroy
@@ -232,11 +240,12 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
     *out = nullptr;
     if (!device_ids || n_dev < 1 || n_dev > ARTMIPS_MAX_DEVICES)
         return fail(ARTMIPS_ERR_ARG, "n_dev must be in [1, %d]", ARTMIPS_MAX_DEVICES);
-    if (storage_dtype != ARTMIPS_F16 && storage_dtype != ARTMIPS_BF16)
-        return fail(ARTMIPS_ERR_UNSUPPORTED, "storage dtype %d: only f16 (0) and bf16 (1) rows",
+    if (storage_dtype != ARTMIPS_F16 && storage_dtype != ARTMIPS_BF16 && storage_dtype != ARTMIPS_F32)
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "storage dtype %d: rows are f16 (0), bf16 (1) or f32 (2)",
                     storage_dtype);
-    if (!dim_supported(dim))
-        return fail(ARTMIPS_ERR_UNSUPPORTED, "dim %d: kernels are built for 128, 768 and 1024", dim);
+    if (!dim_supported(dim, storage_dtype))
+        return fail(ARTMIPS_ERR_UNSUPPORTED,
+                    "dim %d: kernels are built for 128, 768 and 1024 (f16/bf16) or 128 and 768 (f32)", dim);
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     for (int i = 0; i < n_dev; ++i)
@@ -516,6 +525,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     const int qt = p.nq * QGROUP;
     int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;
     if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
+    else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
     else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
     HIP_TRY(hipGetLastError());
 
@@ -598,14 +608,14 @@ static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, in
     int retries = 0;
     for (;;) {
         // up to 256 queries share one sweep over the rows (4 column groups of 64)
-        int nq = (int)std::min<int64_t>((n_q + QGROUP - 1) / QGROUP, max_nq(h->dim));
+        int nq = (int)std::min<int64_t>((n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
         if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
         const int QT = nq * QGROUP;
         const auto t_begin = std::chrono::steady_clock::now();
         Plan p = make_plan(s, gen.n_rows, k, h->cap_boost, nq);
         // workspace
         int rc = 0;
-        if ((rc = ensure(s.qpad, (size_t)QT * h->dim * 2))) return rc;
+        if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
         if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
         if ((rc = ensure(s.status, 64))) return rc;
         if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * SCAN_THREADS * 4))) return rc;

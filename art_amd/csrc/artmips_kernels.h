@@ -81,6 +81,21 @@ template <> struct Elem<__bf16> {
     }
 };
 
+// fp32 storage (BASELINE config 5's tolerance check): exact-f32 MFMA, K = 4 per instruction; a
+// 16-byte fragment holds 4 consecutive k of one row, consumed by 4 chained MFMAs (lane group g of
+// MFMA t multiplies element t of its fragment, for the row operand and the query operand alike).
+template <> struct Elem<float> {
+    typedef f32x4 V;
+    static __device__ __forceinline__ f32x4 mfma(V a, V b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ float from_float(float x) { return x; }
+};
+
 // Orderable 32-bit image of a float: larger float <=> larger unsigned. -0 is folded into +0 so
 // that the two compare equal in the key as they do as floats.
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -272,7 +287,9 @@ __device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, in
     if constexpr (F < NQ * KSTEPS) {
         constexpr int j = F / KSTEPS, s = F % KSTEPS;
         const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
-        const T* src = qrow0 + (size_t)j * QGROUP * (KSTEPS * 32) + chunk * 8;
+        constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+        constexpr int DIMQ = KSTEPS * 4 * EPC;              // row width in elements
+        const T* src = qrow0 + (size_t)j * QGROUP * DIMQ + chunk * EPC;
         if constexpr (ASM_PATH && F >= VB) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[j][s]) : "v"(src) : "memory");
         } else {
@@ -296,11 +313,15 @@ __device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
 template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
-    constexpr int KSTEPS = DIM / 32;       // MFMA 16x16x32 k-steps per row
-    constexpr int CPR = DIM / 8;           // 16-byte chunks per row
-    constexpr int PIECES = TILE_ROWS * DIM * 2 / 1024;  // 1-KiB pieces per 16-row stage
+    constexpr int ES = (int)sizeof(T);     // bytes per stored element
+    constexpr int EPC = 16 / ES;           // elements per 16-byte chunk
+    constexpr int ROWB = DIM * ES;         // bytes per row
+    constexpr int KSTEPS = ROWB / 64;      // k-steps per row: 4 lane groups x one 16-byte chunk each
+    constexpr int CPR = ROWB / 16;         // 16-byte chunks per row
+    constexpr int PIECES = TILE_ROWS * ROWB / 1024;  // 1-KiB pieces per 16-row stage
     constexpr int PPW = PIECES / 4;        // pieces each of the 4 waves issues per stage
-    constexpr int STAGE_BYTES = TILE_ROWS * DIM * 2;
+    constexpr int STAGE_BYTES = TILE_ROWS * ROWB;
+    constexpr int MPF = (ES == 4) ? 4 : 1; // MFMA instructions per fragment
     static_assert(DIM % 128 == 0, "DIM must be a multiple of 128");
     static_assert(PIECES % 4 == 0, "pieces must split evenly over 4 waves");
     static_assert((NSTAGE - 2) * PPW <= 63, "vmcnt field is 6 bits");
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         rd_off[2] = rd_off[3] = 0;
     } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rd_off[m] = r * (DIM * 2) + 16 * ((4 * m + g) ^ r);
+        for (int m = 0; m < 4; ++m) rd_off[m] = r * ROWB + 16 * ((4 * m + g) ^ r);
     }
 
     const long long n_work = a.n_work;
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     for (int pp = 0; pp < PPW; ++pp) {
         const int pos = (w * PPW + pp) * 64 + lane;
         const int trow = pos / CPR;
-        lane_off[pp] = (uint32_t)(trow * (DIM * 2) + (((pos - trow * CPR) ^ (trow & 15)) * 16));
+        lane_off[pp] = (uint32_t)(trow * ROWB + (((pos - trow * CPR) ^ (trow & 15)) * 16));
     }
 
     auto issue_stage = [&](long long it, int slot) {
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         char* slot_base = smem + slot * STAGE_BYTES;
         if (LAYOUT == 1 && row0 + TILE_ROWS <= n_rows) {
             // whole tile in range (all but the last tile): uniform base + per-lane constant
-            const char* tile = (const char*)rows + row0 * (DIM * 2);
+            const char* tile = (const char*)rows + row0 * ROWB;
             const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
 #pragma unroll
             for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
@@ -394,14 +415,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 const int j = p >> 1, half = p & 1;
                 long long row = row0 + 8 * half + rho;
                 if (row > last_row) row = last_row;
-                src = rows + row * DIM + j * 64 + xch * 8;
+                src = rows + row * DIM + (j * 8 + xch) * EPC;
             } else {
                 const int pos = p * 64 + lane;         // 16-byte slot of the stage this lane fills
                 const int trow = pos / CPR;            // row of the tile the slot belongs to
                 const int chunk = (pos - trow * CPR) ^ (trow & 15);
                 long long row = row0 + trow;
                 if (row > last_row) row = last_row;    // short last tile: re-read the last row
-                src = rows + row * DIM + chunk * 8;
+                src = rows + row * DIM + chunk * EPC;
             }
             glds16<AUX>(src, slot_base + p * 1024);
         }
@@ -437,23 +458,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 if constexpr (NQ == 1 || LAYOUT == 0) {
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    // the row fragments are all requested before the first MFMA, so the LDS latency is
-                    // paid once per stage and not once per k-step
-                    V af[KSTEPS];
+                    // the row fragments of a chunk are all requested before its first MFMA, so the LDS
+                    // latency is paid once per chunk and not once per k-step
+                    constexpr int CHB = (KSTEPS > 32) ? 12 : KSTEPS;
+                    static_assert(KSTEPS % CHB == 0, "k-steps must split evenly");
 #pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s) {
-                        if (LAYOUT == 0) af[s] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
-                        else af[s] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
+                    for (int c0 = 0; c0 < KSTEPS; c0 += CHB) {
+                        V af[CHB];
+#pragma unroll
+                        for (int i = 0; i < CHB; ++i) {
+                            const int s = c0 + i;
+                            if (LAYOUT == 0) af[i] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
+                            else af[i] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < CHB; ++i) {
+#pragma unroll
+                            for (int j = 0; j < NQ; ++j) acc[j] = Elem<T>::mfma(af[i], bq[j][c0 + i], acc[j]);
+                        }
+                        // pin the order in the emitted code: the ds_read_b128s, then the MFMAs behind
+                        // counted lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA)
+                        __builtin_amdgcn_sched_group_barrier(0x100, CHB, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, CHB * NQ * MPF, 0);
                     }
-#pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s) {
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) acc[j] = Elem<T>::mfma(af[s], bq[j][s], acc[j]);
-                    }
-                    // pin the order in the emitted code: the ds_read_b128s, then the MFMAs behind counted
-                    // lgkmcnt waits (left alone, hipcc alternates read / wait(0) / MFMA to save VGPRs)
-                    __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS * NQ, 0);
                 } else {
                     // chunks of CH k-steps, row fragments double-buffered in registers
                     V af[2][CH];

@@ -35,8 +35,8 @@ class MipsEngine(object):
     """
 
     def __init__(self, dim, storage_dtype=torch.float16, devices=None):
-        if storage_dtype not in (torch.float16, torch.bfloat16):
-            raise ValueError("storage dtype must be float16 or bfloat16")
+        if storage_dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            raise ValueError("storage dtype must be float16, bfloat16 or float32")
         if devices is None:
             devices = list(range(torch.cuda.device_count()))
         if len(devices) < 1:
@@ -71,8 +71,10 @@ class MipsEngine(object):
         """Append host rows (numpy float16 array, or a CPU torch tensor in the storage dtype)
         and their int32 passage ids."""
         if isinstance(rows, np.ndarray):
-            if self.storage_dtype != torch.float16 or rows.dtype != np.float16:
-                raise ValueError("numpy rows must be float16 for a float16 index")
+            want = {torch.float16: np.float16, torch.float32: np.float32}.get(self.storage_dtype)
+            if want is None or rows.dtype != want:
+                raise ValueError("numpy rows must match the storage dtype (float16 or float32); "
+                                 "pass a CPU torch tensor for bfloat16")
             rows = np.ascontiguousarray(rows)
             n, d = rows.shape
             rows_ptr = rows.ctypes.data

@@ -40,7 +40,7 @@ typedef struct artmips artmips_t;
 enum {
     ARTMIPS_F16 = 0, /* IEEE half  — the reference's storage type (art_index.py:61,247) */
     ARTMIPS_BF16 = 1,
-    ARTMIPS_F32 = 2  /* scores out / queries in only; not a storage type yet */
+    ARTMIPS_F32 = 2  /* storage too (dim 128/768; exact-f32 MFMA, BASELINE config 5's check) */
 };
 
 /* error codes */

@@ -11,6 +11,8 @@ def build_engine(rows, ids, storage=torch.float16, devices=(0,)):
     eng = MipsEngine(rows.shape[1], storage, list(devices))
     if storage == torch.float16:
         eng.build(np.ascontiguousarray(rows, dtype=np.float16), ids)
+    elif storage == torch.float32:
+        eng.build(np.ascontiguousarray(rows, dtype=np.float32), ids)
     else:
         eng.build(torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(storage), ids)
     return eng

@@ -103,6 +103,46 @@ def test_fx_bf16_storage(gu, golden_dir):
     eng.close()
 
 
+def test_fx_fp32_storage_and_c5_tolerance(gu, golden_dir):
+    # BASELINE config 5 in miniature: the same embeddings stored as fp32 and as bf16
+    fx = _load(golden_dir, "fx_bf16_vs_fp32.npz")
+    rows, queries, ids = fx["rows_f32"], fx["queries_f32"], fx["ids"]
+    e32 = gu.build_engine(rows, ids, storage=torch.float32)
+    s32, i32 = gu.search_np(e32, queries, 50, q_dtype=torch.float32)
+    # fp32 storage: exact-f32 MFMA chain, so ids are bit-exact and scores agree to fp32 rounding
+    np.testing.assert_array_equal(i32, fx["ids_f32_k50"])
+    np.testing.assert_allclose(s32, fx["scores_f32_k50"], rtol=2e-6, atol=1e-6)
+    eb = gu.build_engine(rows, ids, storage=torch.bfloat16)
+    sb, ib = gu.search_np(eb, queries, 50, q_dtype=torch.float32)  # queries rounded to bf16 inside
+    # where the fp32 gap to the neighbours exceeds the bf16 error bound the ids must match:
+    # |score| ~ 1.4, bf16 rounding of 768 products gives an absolute error of a few 1e-3
+    full = fx["scores_f32_k50"].astype(np.float64)
+    gap_prev = np.concatenate([np.full((full.shape[0], 1), np.inf), full[:, :-1] - full[:, 1:]], 1)
+    gap_next = np.concatenate([full[:, :-1] - full[:, 1:], np.full((full.shape[0], 1), 0.0)], 1)
+    clear = (gap_prev > 0.03) & (gap_next > 0.03)
+    assert clear.sum() > 20
+    assert np.all(ib[clear] == i32[clear])
+    # scores of the same ids: bf16 storage vs fp32 storage differ by bf16 rounding only
+    common = ib == i32
+    assert np.max(np.abs(sb[common] - s32[common]) / np.maximum(np.abs(s32[common]), 1.0)) < 1e-2
+    # and each engine is within 1e-3 relative of the exact scores of ITS OWN stored data
+    orc.check_topk(sb, ib, orc.to_storage(queries, "bf16"), orc.to_storage(rows, "bf16"), ids, 50, rel_tol=REL_TOL)
+    e32.close()
+    eb.close()
+
+
+def test_fp32_storage_random(gu):
+    rng = np.random.Generator(np.random.PCG64(123))
+    rows = (rng.standard_normal((20011, 768)) * 0.05).astype(np.float32)
+    queries = rng.standard_normal((70, 768)).astype(np.float32)
+    ids = (rng.permutation(20011) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids, storage=torch.float32)
+    s, i = gu.search_np(eng, queries, 32, q_dtype=torch.float32)
+    n_diff = orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float64), ids, 32, rel_tol=1e-5)
+    assert n_diff <= 2
+    eng.close()
+
+
 # ---- seeded random parity against the oracle --------------------------------------------------------
 def _random_case(n, q, dim, seed, scale=0.05):
     rng = np.random.Generator(np.random.PCG64(seed))
