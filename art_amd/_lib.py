@@ -22,6 +22,7 @@ SYMBOLS = (
     "artmips_begin",
     "artmips_upload",
     "artmips_upload_device",
+    "artmips_upload_scatter",
     "artmips_finalize",
     "artmips_search",
     "artmips_search_local",
@@ -77,8 +78,10 @@ def _load():
     lib.artmips_begin.restype = i32
     lib.artmips_upload.argtypes = [vp, vp, vp, i64, i32]
     lib.artmips_upload.restype = i32
-    lib.artmips_upload_device.argtypes = [vp, i32, vp, vp, i64, i64]
+    lib.artmips_upload_device.argtypes = [vp, i32, vp, vp, i64, i64, vp]
     lib.artmips_upload_device.restype = i32
+    lib.artmips_upload_scatter.argtypes = [vp, i32, vp, i32, vp, i64, i64, vp]
+    lib.artmips_upload_scatter.restype = i32
     lib.artmips_finalize.argtypes = [vp]
     lib.artmips_finalize.restype = i32
     lib.artmips_search.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp]

@@ -253,6 +253,31 @@ class DistributedBruteForceIndex(object):
         if _is_main_printer():
             print(">>> Finished adding block data to GPU index", flush=True)
 
+    def add_flat_store(self, flat):
+        """Build the index from an art_amd.flat_store.FlatStore: rows go from the page cache to the
+        GPUs in 64K-row chunks, no Python object per row (not in the reference)."""
+        from .engine import MipsEngine
+
+        want = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[self.storage_dtype]
+        if flat.dtype_code != want or flat.dim != self.embed_size:
+            raise ValueError("flat store is dtype %d dim %d, index expects dtype %d dim %d"
+                             % (flat.dtype_code, flat.dim, want, self.embed_size))
+        engine = MipsEngine(self.embed_size, self.storage_dtype, self.devices)
+        engine.begin(flat.n_rows)
+        for ids, rows in flat.iter_chunks():
+            if self.storage_dtype == torch.bfloat16:
+                engine.upload_host(torch.from_numpy(rows.view(np.int16)).view(torch.bfloat16), ids)
+            else:
+                engine.upload_host(rows, ids)
+        engine.finalize()
+        self._free()
+        self.evidence_embeds = engine
+        self.num_rows = flat.n_rows
+        self.chunksize = -(-flat.n_rows // self.ngpu)
+        self.last_chunksize = flat.n_rows - self.chunksize * (self.ngpu - 1)
+        self.indices_arr = np.asarray(flat.ids).astype(np.int64)
+        self.id_map = _IdMap(self.indices_arr)
+
     def search_mips_index(self, query_embeds, top_k, reconstruct=True):
         """Top-k passages by inner product.
 

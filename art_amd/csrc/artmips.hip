@@ -65,6 +65,7 @@ struct Generation {
     int32_t* ids = nullptr; // [n_rows]
     int64_t n_rows = 0;
     int64_t row0 = 0;       // global index of the shard's first row
+    unsigned long long* meta = nullptr;  // [4] device words: rows scattered, duplicates, unfilled
 };
 
 struct Shard {
@@ -131,6 +132,7 @@ static void release(DevBuf& b) {
 static void free_generation(Generation& g) {
     if (g.rows) (void)hipFree(g.rows);
     if (g.ids) (void)hipFree(g.ids);
+    if (g.meta) (void)hipFree(g.meta);
     g = Generation();
 }
 
@@ -337,6 +339,10 @@ extern "C" int artmips_begin(artmips_t* h, int64_t n_rows_total) {
             const size_t rb = (size_t)s.next.n_rows * h->dim * elem_size(h->dtype);
             hipError_t e = hipMalloc(&s.next.rows, rb);
             if (e == hipSuccess) e = hipMalloc((void**)&s.next.ids, (size_t)s.next.n_rows * 4);
+            if (e == hipSuccess) e = hipMalloc((void**)&s.next.meta, 32);
+            // every id starts as ID_SENTINEL; artmips_finalize refuses a generation that still has one
+            if (e == hipSuccess) e = hipMemset(s.next.ids, 0x80, (size_t)s.next.n_rows * 4);
+            if (e == hipSuccess) e = hipMemset(s.next.meta, 0, 32);
             if (e != hipSuccess) {
                 free_generation(s.next);
                 return fail(ARTMIPS_ERR_NOMEM, "hipMalloc of shard %d (%zu bytes) failed: %s", i, rb,
@@ -408,7 +414,8 @@ extern "C" int artmips_upload(artmips_t* h, const void* host_rows, const int32_t
 }
 
 extern "C" int artmips_upload_device(artmips_t* h, int slot, const void* dev_rows,
-                                     const int32_t* dev_ids, int64_t n, int64_t row_offset) {
+                                     const int32_t* dev_ids, int64_t n, int64_t row_offset,
+                                     void* stream) {
     if (!h || !dev_rows || !dev_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
     if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_upload_device without artmips_begin");
     if (slot < 0 || slot >= h->n_dev) return fail(ARTMIPS_ERR_ARG, "slot %d out of range", slot);
@@ -419,23 +426,98 @@ extern "C" int artmips_upload_device(artmips_t* h, int slot, const void* dev_row
     if (n == 0) return 0;
     DeviceGuard g(s.dev);
     const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
-    // the source may have been produced on another stream (torch's): order against everything
-    HIP_TRY(hipDeviceSynchronize());
+    // asynchronous on the caller's stream (the one that produced the rows); artmips_finalize
+    // synchronises the device before the generation goes live
+    hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync((char*)s.next.rows + (size_t)row_offset * row_bytes, dev_rows,
-                           (size_t)n * row_bytes, hipMemcpyDeviceToDevice, s.stream));
-    HIP_TRY(hipMemcpyAsync(s.next.ids + row_offset, dev_ids, (size_t)n * 4, hipMemcpyDeviceToDevice,
-                           s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));
+                           (size_t)n * row_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.next.ids + row_offset, dev_ids, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+template <typename T>
+static void launch_scatter(const void* src, int src_dtype, const long long* ids, long long n,
+                           long long id_base, const Generation& g, int dim, hipStream_t st) {
+    const int grid = (int)std::min<long long>(n, 4096);
+    hipLaunchKernelGGL(scatter_rows_kernel<T>, dim3(grid), dim3(256), 0, st, src, src_dtype, ids, n, id_base,
+                       (long long)g.row0, (long long)g.n_rows, dim, (T*)g.rows, g.ids, g.meta);
+}
+
+extern "C" int artmips_upload_scatter(artmips_t* h, int src_device, const void* dev_rows, int src_dtype,
+                                      const int64_t* dev_ids, int64_t n, int64_t id_base, void* stream) {
+    if (!h || !dev_rows || !dev_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_upload_scatter without artmips_begin");
+    if (src_dtype < 0 || src_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad source dtype %d", src_dtype);
+    if (n < 0) return fail(ARTMIPS_ERR_ARG, "n must be >= 0");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t src_bytes = (size_t)n * h->dim * elem_size(src_dtype);
+    hipEvent_t ready = h->sh[0].ev_ready;
+    bool recorded = false;
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        if (s.next.n_rows == 0) continue;
+        const void* rows_here = dev_rows;
+        const int64_t* ids_here = dev_ids;
+        hipStream_t run = st;
+        if (s.dev != src_device) {
+            // the batch lives on another GPU: bring it over xGMI once, scatter locally
+            if (!recorded) {
+                DeviceGuard gsrc(src_device);
+                HIP_TRY(hipEventRecord(ready, st));
+                recorded = true;
+            }
+            DeviceGuard g(s.dev);
+            int rc = 0;
+            // the previous batch may still be scattering out of this staging buffer
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            if ((rc = ensure(s.qin, src_bytes))) return rc;
+            if ((rc = ensure(s.loc_ids, (size_t)n * 8))) return rc;
+            HIP_TRY(hipStreamWaitEvent(s.stream, ready, 0));
+            HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, dev_rows, src_device, src_bytes, s.stream));
+            HIP_TRY(hipMemcpyPeerAsync(s.loc_ids.p, s.dev, dev_ids, src_device, (size_t)n * 8, s.stream));
+            rows_here = s.qin.p;
+            ids_here = (const int64_t*)s.loc_ids.p;
+            run = s.stream;
+        }
+        DeviceGuard g(s.dev);
+        if (h->dtype == ARTMIPS_F16)
+            launch_scatter<_Float16>(rows_here, src_dtype, (const long long*)ids_here, n, id_base, s.next, h->dim, run);
+        else if (h->dtype == ARTMIPS_BF16)
+            launch_scatter<__bf16>(rows_here, src_dtype, (const long long*)ids_here, n, id_base, s.next, h->dim, run);
+        else
+            launch_scatter<float>(rows_here, src_dtype, (const long long*)ids_here, n, id_base, s.next, h->dim, run);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
 extern "C" int artmips_finalize(artmips_t* h) {
     if (!h) return fail(ARTMIPS_ERR_ARG, "handle is NULL");
     if (!h->building) return fail(ARTMIPS_ERR_STATE, "artmips_finalize without artmips_begin");
+    // every row must have been uploaded exactly once (the reference asserts the same after its merge:
+    // indexer.py:161 and art_index.py:59,90)
+    unsigned long long missing = 0, dups = 0;
+    for (int i = 0; i < h->n_dev; ++i) {
+        Shard& s = h->sh[i];
+        if (s.next.n_rows == 0) continue;
+        DeviceGuard g(s.dev);
+        HIP_TRY(hipDeviceSynchronize());  // uploads landed
+        hipLaunchKernelGGL(count_unfilled_kernel, dim3(1024), dim3(256), 0, 0, s.next.ids,
+                           (long long)s.next.n_rows, s.next.meta + 2);
+        HIP_TRY(hipGetLastError());
+        unsigned long long meta[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(meta, s.next.meta, 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(s.next.meta + 2, 0, 8));
+        dups += meta[1];
+        missing += meta[2];
+    }
+    if (dups) return fail(ARTMIPS_ERR_STATE, "Unexpectedly tried to overwrite block data: %llu rows were uploaded twice", dups);
+    if (missing) return fail(ARTMIPS_ERR_STATE, "%llu of %lld rows were never uploaded", missing, (long long)h->next_total);
     for (int i = 0; i < h->n_dev; ++i) {
         Shard& s = h->sh[i];
         DeviceGuard g(s.dev);
-        HIP_TRY(hipDeviceSynchronize());  // uploads landed, no search is using the old rows
+        HIP_TRY(hipDeviceSynchronize());  // no search is using the old rows
         free_generation(s.live);
         s.live = s.next;
         s.next = Generation();

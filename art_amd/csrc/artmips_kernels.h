@@ -947,4 +947,51 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     topk_finish(dst, M, in_lds, nullptr, sc, o);
 }
 
+// ---------------------------------------------------------------------------------------------
+// index-refresh upload kernels
+// ---------------------------------------------------------------------------------------------
+constexpr int32_t ID_SENTINEL = (int32_t)0x80808080;  // "row not uploaded yet" (memset byte 0x80)
+
+// Scatter a batch of freshly encoded rows into a shard: row i goes to local position
+// ids[i] - id_base - shard_row0 if that falls inside the shard, converted to the storage dtype.
+// meta[0] counts rows written, meta[1] counts duplicates (a position written twice).
+// One 256-thread workgroup per batch row (grid-strided).
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const void* __restrict__ src, int src_dtype,
+                                                           const long long* __restrict__ ids, long long n,
+                                                           long long id_base, long long shard_row0,
+                                                           long long shard_rows, int dim,
+                                                           T* __restrict__ rows, int32_t* __restrict__ row_ids,
+                                                           unsigned long long* __restrict__ meta) {
+    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long id = ids[i];
+        const long long pos = id - id_base - shard_row0;
+        if (pos < 0 || pos >= shard_rows) continue;  // another shard owns this row (uniform per block)
+        T* dst = rows + pos * dim;
+        for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+            float v;
+            if (src_dtype == 0) v = (float)((const _Float16*)src)[i * dim + c];
+            else if (src_dtype == 1) v = (float)((const __bf16*)src)[i * dim + c];
+            else v = ((const float*)src)[i * dim + c];
+            dst[c] = Elem<T>::from_float(v);
+        }
+        if (threadIdx.x == 0) {
+            const int32_t old = atomicExch(&row_ids[pos], (int32_t)id);
+            if (old != ID_SENTINEL) atomicAdd(&meta[1], 1ull);
+            else atomicAdd(&meta[0], 1ull);
+        }
+    }
+}
+
+// how many rows of a shard were never uploaded
+__global__ void count_unfilled_kernel(const int32_t* __restrict__ row_ids, long long n,
+                                      unsigned long long* __restrict__ out) {
+    unsigned long long mine = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        mine += (row_ids[i] == ID_SENTINEL) ? 1ull : 0ull;
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 }  // namespace artk

@@ -103,8 +103,30 @@ class MipsEngine(object):
         n, d = rows.shape
         if d != self.dim or ids.shape != (n,):
             raise ValueError("shape mismatch")
-        check(lib.artmips_upload_device(self._h, int(slot), ctypes.c_void_p(rows.data_ptr()),
-                                        ctypes.c_void_p(ids.data_ptr()), n, int(row_offset)))
+        with torch.cuda.device(rows.device):
+            check(lib.artmips_upload_device(self._h, int(slot), ctypes.c_void_p(rows.data_ptr()),
+                                            ctypes.c_void_p(ids.data_ptr()), n, int(row_offset),
+                                            _stream_ptr(rows.device)))
+
+    def upload_scatter(self, rows, ids, id_base=1):
+        """Scatter a batch of rows on a GPU (float16/bfloat16/float32, converted to the storage
+        dtype) into the generation being built: the row with passage id `id` lands at global position
+        id - id_base.  Asynchronous on torch's current stream (the sources may be freed right away:
+        torch's allocator reuses memory in stream order).  Single-GPU sources only cross to other
+        devices' shards through a staging copy inside the library."""
+        if not rows.is_cuda or not ids.is_cuda or rows.device != ids.device:
+            raise ValueError("rows and ids must live on the same GPU")
+        if ids.dtype != torch.int64:
+            ids = ids.to(torch.int64)
+        rows = rows.contiguous()
+        ids = ids.contiguous()
+        n, d = rows.shape
+        if d != self.dim or ids.shape != (n,):
+            raise ValueError("shape mismatch")
+        with torch.cuda.device(rows.device):
+            check(lib.artmips_upload_scatter(self._h, rows.device.index, ctypes.c_void_p(rows.data_ptr()),
+                                             _abi_dtype(rows.dtype), ctypes.c_void_p(ids.data_ptr()), n,
+                                             int(id_base), _stream_ptr(rows.device)))
 
     def finalize(self):
         check(lib.artmips_finalize(self._h))

@@ -1,0 +1,171 @@
+"""Index refresh without the pickle round trip.
+
+The reference refreshes its index through the filesystem: every encoder rank copies its
+embeddings to the host, inserts them row by row into a dict, pickles a shard, rank 0 merges the
+shards into one 32 GB pickle (indexer.py:146-165, art_index.py:56-100), and the index owner
+unpickles it and re-uploads everything (art_index.py:231-265).  Here the encoder output stays on
+the GPU: batches are scattered by passage id straight into the next generation of the index,
+which is swapped in atomically when every row has arrived.  The index ends up in id order
+(row position = id - id_base), independent of the order the batches came in.
+
+Two sinks with the store's ``add_block_data(row_id, block_embeds)`` signature:
+
+  DeviceIndexWriter   one process owns every shard (the reference's process model)
+  SpmdIndexWriter     one process per GPU, each owning the rows [lo, hi) of the id range; batches
+                      are exchanged by owner with all_to_all at commit time
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import ArtmipsError
+from .distributed import shard_bounds
+
+
+def _as_cuda(row_id, block_embeds, device):
+    if isinstance(row_id, np.ndarray):
+        row_id = torch.from_numpy(np.ascontiguousarray(row_id).astype(np.int64))
+    if isinstance(block_embeds, np.ndarray):
+        block_embeds = torch.from_numpy(np.ascontiguousarray(block_embeds))
+    row_id = row_id.detach().to(device=device, dtype=torch.int64).reshape(-1)
+    block_embeds = block_embeds.detach().to(device=device)
+    if block_embeds.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        block_embeds = block_embeds.float()
+    if block_embeds.dim() != 2 or block_embeds.shape[0] != row_id.shape[0]:
+        raise ValueError("block_embeds must be [len(row_id), dim]")
+    return row_id, block_embeds.contiguous()
+
+
+def _finalize(engine):
+    try:
+        engine.finalize()
+    except ArtmipsError as e:
+        if "overwrite block data" in str(e):
+            # the reference's duplicate-id error (art_index.py:59)
+            raise ValueError("Unexpectedly tried to overwrite block data") from e
+        raise
+
+
+class DeviceIndexWriter(object):
+    """Builds the next generation of a DistributedBruteForceIndex from device batches.
+
+    index: art_amd.art_index.DistributedBruteForceIndex (searches keep hitting the live
+    generation until commit()).  n_rows: number of passages; their ids must be exactly
+    id_base .. id_base + n_rows - 1 (the evidence dataset uses row_id = idx + 1,
+    pretokenized_evidence.py:63-64).
+    """
+
+    def __init__(self, index, n_rows, id_base=1):
+        from .engine import MipsEngine
+
+        self.index = index
+        self.n_rows = int(n_rows)
+        self.id_base = int(id_base)
+        self._own_engine = index.evidence_embeds is None
+        self.engine = index.evidence_embeds
+        if self.engine is None:
+            self.engine = MipsEngine(index.embed_size, index.storage_dtype, index.devices)
+        self.device = torch.device("cuda", self.engine.devices[0])
+        self.engine.begin(self.n_rows)
+
+    def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
+        if allow_overwrite:
+            raise ValueError("allow_overwrite is not supported by the device refresh path")
+        row_id, block_embeds = _as_cuda(row_id, block_embeds, self.device)
+        self.engine.upload_scatter(block_embeds, row_id, self.id_base)
+
+    def commit(self):
+        """Swap the new generation in.  Raises ValueError if a passage id was added twice and
+        ArtmipsError if some passage never arrived (the reference: art_index.py:59, indexer.py:161)."""
+        _finalize(self.engine)
+        idx = self.index
+        idx.evidence_embeds = self.engine
+        idx.num_rows = self.n_rows
+        idx.chunksize = -(-self.n_rows // idx.ngpu)
+        idx.last_chunksize = self.n_rows - idx.chunksize * (idx.ngpu - 1)
+        idx.indices_arr = np.arange(self.id_base, self.id_base + self.n_rows, dtype=np.int64)
+        from .art_index import _IdMap
+
+        idx.id_map = _IdMap(idx.indices_arr)
+
+
+def route_by_owner(row_id, block_embeds, n_rows, id_base, world):
+    """Sort a batch by owning rank (torch.chunk row ranges over positions id - id_base).
+    Returns (ids sorted, rows sorted, rows per destination rank as a python list)."""
+    chunk = -(-n_rows // world)
+    pos = row_id - id_base
+    if row_id.numel() and (int(pos.min()) < 0 or int(pos.max()) >= n_rows):
+        raise ValueError("passage id outside [%d, %d)" % (id_base, id_base + n_rows))
+    dest = torch.div(pos, chunk, rounding_mode="floor")
+    order = torch.argsort(dest, stable=True)
+    counts = torch.bincount(dest, minlength=world).tolist()
+    return row_id[order], block_embeds[order], counts
+
+
+class SpmdIndexWriter(object):
+    """One process per GPU: this rank's engine (one shard) receives the rows whose position
+    id - id_base falls in its torch.chunk range; everything else is sent to its owner.
+
+    add_block_data() only buffers (on the device, in the encoder's dtype); commit() is
+    collective: an all_to_all of the row counts, one of the ids, one of the rows (RCCL over xGMI
+    with the "nccl" backend), a scatter into the local shard, and the swap.
+    `sink(rows, ids, id_base_local)` defaults to engine.upload_scatter and exists so that the
+    exchange can be tested on the CPU with gloo.
+    """
+
+    def __init__(self, engine, n_rows, id_base=1, group=None, sink=None, device=None):
+        self.engine = engine
+        self.n_rows = int(n_rows)
+        self.id_base = int(id_base)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi = shard_bounds(self.n_rows, self.world)[self.rank]
+        if device is None:
+            device = torch.device("cuda", engine.devices[0])
+        self.device = device
+        self._sink = sink if sink is not None else engine.upload_scatter
+        self._ids, self._rows = [], []
+        if engine is not None:
+            engine.begin(self.hi - self.lo)
+
+    def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
+        if allow_overwrite:
+            raise ValueError("allow_overwrite is not supported by the device refresh path")
+        if self.device.type == "cuda":
+            row_id, block_embeds = _as_cuda(row_id, block_embeds, self.device)
+        self._ids.append(row_id.reshape(-1).to(torch.int64))
+        self._rows.append(block_embeds)
+
+    def commit(self):
+        dim = self.engine.dim if self.engine is not None else (self._rows[0].shape[1] if self._rows else 0)
+        if self._ids:
+            ids = torch.cat(self._ids)
+            rows = torch.cat(self._rows)
+        else:
+            ids = torch.empty(0, dtype=torch.int64, device=self.device)
+            rows = torch.empty((0, dim), dtype=torch.float16, device=self.device)
+        self._ids, self._rows = [], []
+        ids, rows, send = route_by_owner(ids, rows, self.n_rows, self.id_base, self.world)
+        if self.world > 1:
+            # "nccl" (RCCL) exchanges device buffers directly; gloo (CPU tests, or two ranks sharing
+            # one GPU in the test-suite) goes through host copies
+            xdev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            ids, rows = ids.to(xdev), rows.contiguous().to(xdev)
+            send_t = torch.tensor(send, dtype=torch.int64, device=xdev)
+            recv_t = torch.empty_like(send_t)
+            dist.all_to_all_single(recv_t, send_t, group=self.group)
+            recv = recv_t.tolist()
+            ids_in = torch.empty(sum(recv), dtype=torch.int64, device=xdev)
+            dist.all_to_all_single(ids_in, ids, recv, send, group=self.group)
+            rows_in = torch.empty((sum(recv), rows.shape[1]), dtype=rows.dtype, device=xdev)
+            dist.all_to_all_single(rows_in, rows, recv, send, group=self.group)
+            ids, rows = ids_in.to(self.device), rows_in.to(self.device)
+        if ids.numel():
+            self._sink(rows, ids, self.id_base + self.lo)
+        if self.engine is not None:
+            _finalize(self.engine)
+        return int(ids.numel())
+
+
+__all__ = ["DeviceIndexWriter", "SpmdIndexWriter", "route_by_owner"]

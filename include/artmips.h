@@ -99,13 +99,29 @@ int artmips_upload(artmips_t* h, const void* host_rows, const int32_t* ids, int6
                    int flags);
 
 /* Copy n rows that already live on a device into shard `slot` at row_offset
- * (offset inside that shard).  The index-refresh path without the pickle round
- * trip (indexer.py:146-165 -> art_index.py:231-265). */
+ * (offset inside that shard), asynchronously on `stream`.  The index-refresh path
+ * without the pickle round trip (indexer.py:146-165 -> art_index.py:231-265) when
+ * the caller already knows where its rows go. */
 int artmips_upload_device(artmips_t* h, int slot, const void* dev_rows, const int32_t* dev_ids,
-                          int64_t n, int64_t row_offset);
+                          int64_t n, int64_t row_offset, void* stream);
+
+/* Scatter a batch of freshly encoded rows (on device `src_device`, dtype src_dtype,
+ * converted to the storage dtype) into the generation being built: the row with
+ * passage id `id` lands at global position id - id_base, i.e. the index ends up in
+ * id order whatever order the encoder ranks deliver their batches in.  Replaces
+ * detach() + add_block_data (indexer.py:146-149, art_index.py:56-61) + the shard
+ * pickles (art_index.py:63-100) + the re-upload (art_index.py:231-265).
+ * Asynchronous on `stream`.  A row uploaded twice or never is reported by
+ * artmips_finalize (the reference's ValueError at art_index.py:59 and the
+ * indexer's completeness assert at indexer.py:161).  Ids must not be
+ * -2139062144 (the "not uploaded yet" marker). */
+int artmips_upload_scatter(artmips_t* h, int src_device, const void* dev_rows, int src_dtype,
+                           const int64_t* dev_ids, int64_t n, int64_t id_base, void* stream);
 
 /* Make the generation being built the live index and free the old one.
- * Replaces the tail of add_embed_data / update_index (art_index.py:231-265). */
+ * Fails (ARTMIPS_ERR_STATE, generation kept) if a row was never uploaded or was
+ * scattered twice.  Replaces the tail of add_embed_data / update_index
+ * (art_index.py:231-265). */
 int artmips_finalize(artmips_t* h);
 
 /* Replaces DistributedBruteForceIndex.search_mips_index (art_index.py:267-304):

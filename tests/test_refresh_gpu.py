@@ -1,0 +1,140 @@
+"""GPU tests of the index-refresh upload path: device batches scattered by passage id into the next
+generation (no pickle round trip), atomic swap, integrity errors, flat-store upload, and the SPMD
+exchange with two ranks sharing the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import mips_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n=5000, dim=768, seed=4):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = (rng.standard_normal((n, dim)) * 0.05).astype(np.float32)
+    queries = rng.standard_normal((9, dim)).astype(np.float16)
+    return rows, queries
+
+
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_device_writer_equals_store_path(tmp_path, n_shards):
+    from art_amd.art_index import DistributedBruteForceIndex, OpenRetreivalDataStore
+    from art_amd.refresh import DeviceIndexWriter
+    assert torch.cuda.is_available()
+    rows, queries = _data()
+    n = rows.shape[0]
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    # reference protocol: store -> index
+    store = OpenRetreivalDataStore(str(tmp_path / "e.pkl"), load_from_path=False, rank=0)
+    store.add_block_data(ids, rows)
+    ref_index = DistributedBruteForceIndex(768, store, devices=[0] * n_shards)
+    ref_index.score_dtype = torch.float32
+    q = torch.from_numpy(queries).cuda()
+    s_ref, i_ref = ref_index.search_mips_index(q, 40)
+
+    # refresh protocol: fp32 encoder output on the GPU, batches of 128 in shuffled order
+    index = DistributedBruteForceIndex(768, None, devices=[0] * n_shards)
+    index.score_dtype = torch.float32
+    w = DeviceIndexWriter(index, n, id_base=1)
+    perm = np.random.Generator(np.random.PCG64(0)).permutation(n)
+    d_rows = torch.from_numpy(rows).cuda()
+    for b in range(0, n, 128):
+        sel = torch.from_numpy(perm[b:b + 128]).cuda()
+        w.add_block_data(sel + 1, d_rows[sel])
+    w.commit()
+    assert index.num_rows == n and index.indices_arr[0] == 1 and index.indices_arr[-1] == n
+    s, i = index.search_mips_index(q, 40)
+    assert torch.equal(i, i_ref) and torch.equal(s, s_ref)  # same fp16 rounding, same kernels
+    orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64),
+                   rows.astype(np.float16).astype(np.float64), ids, 40, rel_tol=1e-3)
+
+    # second refresh on the live index: the old generation keeps answering until commit
+    rows2 = rows.copy()
+    rows2[17] = queries[0].astype(np.float32) * 3  # id 18 becomes the clear winner for query 0
+    w2 = DeviceIndexWriter(index, n, id_base=1)
+    w2.add_block_data(torch.arange(1, n // 2 + 1).cuda(), torch.from_numpy(rows2[:n // 2]).cuda())
+    s_mid, i_mid = index.search_mips_index(q, 40)
+    assert torch.equal(i_mid, i_ref)
+    w2.add_block_data(np.arange(n // 2 + 1, n + 1), rows2[n // 2:])  # numpy batches work too
+    w2.commit()
+    s2, i2 = index.search_mips_index(q, 40)
+    assert int(i2[0, 0]) == 18
+
+
+def test_refresh_integrity_errors():
+    from art_amd._lib import ArtmipsError
+    from art_amd.art_index import DistributedBruteForceIndex
+    from art_amd.refresh import DeviceIndexWriter
+    rows, _ = _data(n=300)
+    d_rows = torch.from_numpy(rows).cuda()
+    index = DistributedBruteForceIndex(768, None, devices=[0, 0])
+    w = DeviceIndexWriter(index, 300)
+    w.add_block_data(torch.arange(1, 301).cuda(), d_rows)
+    w.add_block_data(torch.tensor([5]).cuda(), d_rows[:1])  # id 5 twice
+    with pytest.raises(ValueError) as e:
+        w.commit()
+    assert "overwrite block data" in str(e.value)
+    w = DeviceIndexWriter(index, 300)
+    w.add_block_data(torch.arange(1, 300).cuda(), d_rows[:299])  # id 300 never arrives
+    with pytest.raises(ArtmipsError) as e:
+        w.commit()
+    assert "never uploaded" in str(e.value)
+
+
+def test_flat_store_upload(tmp_path):
+    from art_amd.art_index import DistributedBruteForceIndex
+    from art_amd.flat_store import FlatStore, write_flat
+    rows, queries = _data(n=3000)
+    ids = (np.random.Generator(np.random.PCG64(2)).permutation(3000) + 1).astype(np.int64)
+    path = str(tmp_path / "e.flat")
+    write_flat(path, ids, rows.astype(np.float16))
+    index = DistributedBruteForceIndex(768, None, devices=[0, 0])
+    index.add_flat_store(FlatStore(path))
+    index.score_dtype = torch.float32
+    s, i = index.search_mips_index(torch.from_numpy(queries).cuda(), 25)
+    orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64),
+                   rows.astype(np.float16).astype(np.float64), ids, 25, rel_tol=1e-3)
+    assert np.all(np.diff(index.indices_arr) > 0)
+
+
+def _spmd_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd.distributed import engine_spmd_search
+        from art_amd.engine import MipsEngine
+        from art_amd.refresh import SpmdIndexWriter
+        torch.cuda.set_device(0)
+        rows, queries = _data(n=4001)
+        n = rows.shape[0]
+        eng = MipsEngine(768, torch.float16, [0])
+        w = SpmdIndexWriter(eng, n, id_base=1)
+        mine = np.arange(rank, n, world)
+        for b in range(0, len(mine), 128):
+            sel = mine[b:b + 128]
+            w.add_block_data(torch.from_numpy(sel + 1).cuda(), torch.from_numpy(rows[sel]).cuda())
+        w.commit()
+        s, i = engine_spmd_search(eng, torch.from_numpy(queries).cuda(), 30, score_dtype=torch.float32)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "s%d.npy" % rank), s.cpu().numpy())
+        np.save(os.path.join(out_dir, "i%d.npy" % rank), i.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spmd_writer_two_ranks_one_gpu(tmp_path):
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_spmd_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rows, queries = _data(n=4001)
+    ids = np.arange(1, 4002, dtype=np.int64)
+    for r in range(2):
+        s, i = np.load(tmp_path / ("s%d.npy" % r)), np.load(tmp_path / ("i%d.npy" % r))
+        orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float16).astype(np.float64), ids, 30,
+                       rel_tol=1e-3)
