@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Throughput of the index-refresh upload paths on one GPU:
+  host     artmips_upload from a contiguous host array (pinned double-buffered H2D)
+  scatter  artmips_upload_scatter of fp16 / fp32 device batches of 128*world rows (the indexer's batch)
+  dict     the reference protocol: dict store -> chunks -> artmips_upload (Python bound)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from art_amd.art_index import DistributedBruteForceIndex, OpenRetreivalDataStore  # noqa: E402
+from art_amd.engine import MipsEngine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+dim = 768
+rows = np.random.default_rng(0).standard_normal((n, dim), dtype=np.float32).astype(np.float16)
+ids = np.arange(1, n + 1, dtype=np.int32)
+gb = n * dim * 2 / 1e9
+
+eng = MipsEngine(dim, torch.float16, [0])
+eng.build(rows[:1000], ids[:1000])  # warm the pinned buffers
+t0 = time.perf_counter()
+eng.begin(n); eng.upload_host(rows, ids); eng.finalize()
+t = time.perf_counter() - t0
+print(json.dumps({"path": "host", "rows": n, "GB": gb, "seconds": t, "GB_per_s": gb / t}), flush=True)
+
+for dt, name in ((torch.float16, "scatter fp16 batches"), (torch.float32, "scatter fp32 batches")):
+    d_rows = torch.from_numpy(rows).cuda().to(dt)
+    d_ids = torch.arange(1, n + 1, device="cuda", dtype=torch.int64)
+    perm = torch.randperm(n, device="cuda")
+    batch = 1024
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.begin(n)
+    for b in range(0, n, batch):
+        sel = perm[b:b + batch]
+        eng.upload_scatter(d_rows[sel], d_ids[sel], 1)
+    eng.finalize()
+    t = time.perf_counter() - t0
+    print(json.dumps({"path": name, "rows": n, "batch": batch, "GB_stored": gb, "seconds": t,
+                      "rows_per_s": n / t, "GB_per_s_stored": gb / t}), flush=True)
+    del d_rows
+
+m = min(n, 200000)
+store = OpenRetreivalDataStore("/tmp/_bench_store.pkl", load_from_path=False, rank=0)
+t0 = time.perf_counter()
+store.add_block_data(np.arange(1, m + 1, dtype=np.int64), rows[:m])
+t_add = time.perf_counter() - t0
+t0 = time.perf_counter()
+DistributedBruteForceIndex(dim, store, devices=[0])
+t_idx = time.perf_counter() - t0
+print(json.dumps({"path": "dict store (reference protocol)", "rows": m, "add_block_data_s": t_add,
+                  "add_embed_data_s": t_idx, "rows_per_s_upload": m / t_idx}), flush=True)
