@@ -677,73 +677,103 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
 
 // Full local search of one shard for n_q queries, enqueued on st; outputs [n_q, k].
 // Returns after the stream has been synchronised and overflow retries (if any) are done.
-static int search_shard(artmips* h, int slot, const void* q_dev, int q_dtype, int64_t n_q, int k,
-                        void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
-                        bool record_stats) {
-    Shard& s = h->sh[slot];
+struct ShardCall {
+    int slot;
+    const void* q_dev;
+    int q_dtype;
+    int64_t n_q;
+    int k;
+    void* out_scores;
+    int score_dtype;
+    int32_t* out_ids;
+    hipStream_t st;
+    bool record_stats;
+    int n_tiles_q = 0;
+    std::chrono::steady_clock::time_point t_begin, t_enq;
+};
+
+// Plan, size the scratch and enqueue the whole pipeline of one shard (every query tile) plus the
+// copy of its status words to pinned host memory.  Does not wait.
+static int shard_enqueue(artmips* h, ShardCall& c) {
+    Shard& s = h->sh[c.slot];
     const Generation& gen = s.live;
     DeviceGuard g(s.dev);
-    if (gen.n_rows == 0) {
-        return fail(ARTMIPS_ERR_STATE, "shard %d is empty", slot);
+    if (gen.n_rows == 0) return fail(ARTMIPS_ERR_STATE, "shard %d is empty", c.slot);
+    const size_t q_row_bytes = (size_t)h->dim * elem_size(c.q_dtype);
+    // up to 256 queries share one sweep over the rows (4 column groups of 64)
+    int nq = (int)std::min<int64_t>((c.n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
+    if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
+    const int QT = nq * QGROUP;
+    c.t_begin = std::chrono::steady_clock::now();
+    Plan p = make_plan(s, gen.n_rows, c.k, h->cap_boost, nq);
+    int rc = 0;
+    if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
+    if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
+    if ((rc = ensure(s.status, 64))) return rc;
+    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * SCAN_THREADS * 4))) return rc;
+    if ((rc = ensure(s.counts, (size_t)p.grid * nq * SCAN_THREADS * 4))) return rc;
+    const size_t list_entries = (size_t)p.grid * nq * SCAN_THREADS * (size_t)p.cap;
+    if ((rc = ensure(s.lists, list_entries * 8))) return rc;
+    // global key scratch: worst case every list of a query is full
+    const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
+    if (keys_per_q > (size_t)SORT_MAX) {
+        if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
     }
-    const size_t q_row_bytes = (size_t)h->dim * elem_size(q_dtype);
-    int retries = 0;
+    if (c.record_stats) HIP_TRY(hipEventRecord(s.ev_t0, c.st));
+    c.n_tiles_q = 0;
+    for (int64_t q0 = 0; q0 < c.n_q; q0 += QT, ++c.n_tiles_q) {
+        const int qc = (int)std::min<int64_t>(QT, c.n_q - q0);
+        rc = enqueue_tile(h, s, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
+                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q);
+        if (rc) return rc;
+    }
+    if (c.record_stats) HIP_TRY(hipEventRecord(s.ev_t1, c.st));
+    HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, c.st));
+    c.t_enq = std::chrono::steady_clock::now();
+    return 0;
+}
+
+// Wait for a shard's pipeline and read its status.  *overflow is set when a candidate list
+// overflowed: the result may have lost a top-k member and the shard must be searched again with
+// larger lists.
+static int shard_complete(artmips* h, ShardCall& c, bool* overflow) {
+    Shard& s = h->sh[c.slot];
+    DeviceGuard g(s.dev);
+    HIP_TRY(hipStreamSynchronize(c.st));
+    const auto t_syn = std::chrono::steady_clock::now();
+    *overflow = false;
+    const int status = s.status_host[0];
+    if (status & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
+    if (status & 1) { *overflow = true; return 0; }
+    if (c.record_stats) {
+        h->host_enqueue_us = std::chrono::duration<double, std::micro>(c.t_enq - c.t_begin).count();
+        h->host_sync_us = std::chrono::duration<double, std::micro>(t_syn - c.t_enq).count();
+        h->stats_slot = c.slot;
+        h->stats_tiles = c.n_tiles_q;
+        h->stats_pending = true;  // event times are read when artmips_info asks for them
+        unsigned long long n = 0;
+        memcpy(&n, s.status_host + 2, 8);
+        h->last_candidates = (int64_t)n;
+    }
+    return 0;
+}
+
+// Full local search of one shard; returns with the stream synchronised and overflow retries (if
+// any) done.  At cap == rows-per-lane overflow is impossible, so the retry loop ends.
+static int search_shard(artmips* h, ShardCall c, int retries_so_far = 0) {
+    int retries = retries_so_far;
     for (;;) {
-        // up to 256 queries share one sweep over the rows (4 column groups of 64)
-        int nq = (int)std::min<int64_t>((n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
-        if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
-        const int QT = nq * QGROUP;
-        const auto t_begin = std::chrono::steady_clock::now();
-        Plan p = make_plan(s, gen.n_rows, k, h->cap_boost, nq);
-        // workspace
-        int rc = 0;
-        if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
-        if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
-        if ((rc = ensure(s.status, 64))) return rc;
-        if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * SCAN_THREADS * 4))) return rc;
-        if ((rc = ensure(s.counts, (size_t)p.grid * nq * SCAN_THREADS * 4))) return rc;
-        const size_t list_entries = (size_t)p.grid * nq * SCAN_THREADS * (size_t)p.cap;
-        if ((rc = ensure(s.lists, list_entries * 8))) return rc;
-        // global key scratch: worst case every list of a query is full
-        const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
-        if (keys_per_q > (size_t)SORT_MAX) {
-            if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
+        int rc = shard_enqueue(h, c);
+        if (rc) return rc;
+        bool overflow = false;
+        if ((rc = shard_complete(h, c, &overflow))) return rc;
+        if (!overflow) {
+            if (c.record_stats) h->last_retries = retries;
+            return 0;
         }
-        if (record_stats) HIP_TRY(hipEventRecord(s.ev_t0, st));
-        int n_tiles_q = 0;
-        for (int64_t q0 = 0; q0 < n_q; q0 += QT, ++n_tiles_q) {
-            const int qc = (int)std::min<int64_t>(QT, n_q - q0);
-            rc = enqueue_tile(h, s, p, (const char*)q_dev + (size_t)q0 * q_row_bytes, q_dtype, qc, k,
-                              out_scores, score_dtype, out_ids, q0, st, n_tiles_q);
-            if (rc) return rc;
-        }
-        if (record_stats) HIP_TRY(hipEventRecord(s.ev_t1, st));
-        HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, st));
-        const auto t_enq = std::chrono::steady_clock::now();
-        HIP_TRY(hipStreamSynchronize(st));
-        const auto t_syn = std::chrono::steady_clock::now();
-        h->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - t_begin).count();
-        h->host_sync_us = std::chrono::duration<double, std::micro>(t_syn - t_enq).count();
-        const int status = s.status_host[0];
-        if (status & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
-        if (status & 1) {
-            // a candidate list overflowed: the result may have lost a top-k member.  Enlarge the
-            // lists and rescan; at cap == rows-per-lane overflow is impossible, so this ends.
-            ++retries;
-            if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
-            h->cap_boost *= 8;
-            continue;
-        }
-        if (record_stats) {
-            h->stats_slot = slot;
-            h->stats_tiles = n_tiles_q;
-            h->stats_pending = true;  // event times are read when artmips_info asks for them
-            h->last_retries = retries;
-            unsigned long long c = 0;
-            memcpy(&c, s.status_host + 2, 8);
-            h->last_candidates = (int64_t)c;
-        }
-        return 0;
+        ++retries;
+        if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
+        h->cap_boost *= 8;
     }
 }
 
@@ -768,8 +798,8 @@ extern "C" int artmips_search_local(artmips_t* h, int slot, const void* q_dev, i
         return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k, ARTMIPS_MAX_K,
                     (long long)n_local);
     if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
-    return search_shard(h, slot, q_dev, q_dtype, n_q, k, out_scores, ARTMIPS_F32, out_ids,
-                        (hipStream_t)stream, true);
+    ShardCall c{slot, q_dev, q_dtype, n_q, k, out_scores, ARTMIPS_F32, out_ids, (hipStream_t)stream, true};
+    return search_shard(h, c);
 }
 
 // Scratch of the handle-less artmips_merge: one (status, keys) pair per device, kept for the life
@@ -849,7 +879,8 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
     }
     hipStream_t st = (hipStream_t)stream;
     if (active == 1 && h->sh[0].live.n_rows > 0) {
-        return search_shard(h, 0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, true);
+        ShardCall c{0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, true};
+        return search_shard(h, c);
     }
     // several shards driven by this one process (the reference's model, art_index.py:273-291):
     // replicate the queries, search every shard on its own stream, bring the (score, id) lists
@@ -876,14 +907,27 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
         HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
         used.push_back(i);
     }
-    // the shard pipelines synchronise their own stream (status word), so they run one after the
-    // other from this thread; the kernels of different devices still overlap because every
-    // pipeline is fully enqueued before its synchronise and device queues are independent.
+    // enqueue every shard's pipeline on its own stream first, so that the devices work at the same
+    // time; then collect them one by one.  A shard whose candidate lists overflowed is searched
+    // again on its own (larger lists) before its result is shipped.
+    std::vector<ShardCall> calls;
     for (int i : used) {
         Shard& s = h->sh[i];
-        rc = search_shard(h, i, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
-                          (int32_t*)s.loc_ids.p, s.stream, i == used[0]);
-        if (rc) return rc;
+        calls.push_back(ShardCall{i, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
+                                  (int32_t*)s.loc_ids.p, s.stream, i == used[0]});
+        if ((rc = shard_enqueue(h, calls.back()))) return rc;
+    }
+    for (ShardCall& c : calls) {
+        Shard& s = h->sh[c.slot];
+        bool overflow = false;
+        if ((rc = shard_complete(h, c, &overflow))) return rc;
+        if (overflow) {
+            if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
+            h->cap_boost *= 8;
+            if ((rc = search_shard(h, c, 1))) return rc;
+        } else if (c.record_stats) {
+            h->last_retries = 0;
+        }
         DeviceGuard g(s.dev);
         HIP_TRY(hipMemcpyPeerAsync((char*)h->g_scores.p + (size_t)li * list_elems * 4, s0.dev,
                                    s.loc_scores.p, s.dev, list_elems * 4, s.stream));
