@@ -139,15 +139,15 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1>
+template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1, int STG = 1>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
-    const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T);
+    const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
     static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
     if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ, STG>;
         if (!attr_done[dev][0]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -155,7 +155,7 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ, STG>;
         if (!attr_done[dev][1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -176,49 +176,58 @@ static int scan_variant() {
 
 // Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
 // DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
-template <typename T>
+// stg: stage survivors in LDS (1, few survivors per lane: k <= 128) or store them straight to the
+// HBM lists (0, many survivors per lane: the staging would flush all the time)
+template <typename T, int STG>
 static int launch_scan_dt(int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dim == 768) {
         if (nq == 1) {
             if (sizeof(T) == 2 && scan_variant() != 0) {
-                switch (scan_variant()) {  // experimental builds for tools/scan_sweep.py
+                switch (scan_variant()) {  // experimental builds for tools/scan_sweep.py, sample_sweep.py
                     case 1: return launch_scan_t<T, 768, 6, 0, 2>(mode, a, grid, st);
                     case 2: return launch_scan_t<T, 768, 6, 1, 0>(mode, a, grid, st);
                     case 3: return launch_scan_t<T, 768, 6, 0, 0>(mode, a, grid, st);
                     case 4: return launch_scan_t<T, 768, 3, 1, 2>(mode, a, grid, st);
+                    case 5: return launch_scan_t<T, 768, 6, 1, 2, 1, 0>(mode, a, grid, st);
+                    case 6: return launch_scan_t<T, 768, 5, 1, 2, 1, 1>(mode, a, grid, st);
                     default: break;
                 }
             }
-            return launch_scan_t<T, 768, 6, 1, 2, 1>(mode, a, grid, st);
+            return launch_scan_t<T, 768, 6, 1, 2, 1, STG>(mode, a, grid, st);
         }
-        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2>(mode, a, grid, st);
-        if (nq == 3) return launch_scan_t<T, 768, 6, 1, 2, 3>(mode, a, grid, st);
-        if (nq == 4) return launch_scan_t<T, 768, 6, 1, 2, 4>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2, STG>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 768, 6, 1, 2, 3, STG>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 768, 6, 1, 2, 4, STG>(mode, a, grid, st);
     }
     if (dim == 1024) {
-        if (nq == 1) return launch_scan_t<T, 1024, 4, 1, 2, 1>(mode, a, grid, st);
-        if (nq == 2) return launch_scan_t<T, 1024, 4, 1, 2, 2>(mode, a, grid, st);
+        if (nq == 1) return launch_scan_t<T, 1024, 4, 1, 2, 1, STG>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 1024, 4, 1, 2, 2, STG>(mode, a, grid, st);
     }
     if (dim == 128) {
-        if (nq == 1) return launch_scan_t<T, 128, 8, 1, 2, 1>(mode, a, grid, st);
-        if (nq == 2) return launch_scan_t<T, 128, 8, 1, 2, 2>(mode, a, grid, st);
-        if (nq == 3) return launch_scan_t<T, 128, 8, 1, 2, 3>(mode, a, grid, st);
-        if (nq == 4) return launch_scan_t<T, 128, 8, 1, 2, 4>(mode, a, grid, st);
+        if (nq == 1) return launch_scan_t<T, 128, 8, 1, 2, 1, STG>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 128, 8, 1, 2, 2, STG>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 128, 8, 1, 2, 3, STG>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 128, 8, 1, 2, 4, STG>(mode, a, grid, st);
     }
     return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d nq=%d", dim, nq);
 }
 
 // Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
 // DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
-static int launch_scan(int dtype, int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
-    if (dtype == ARTMIPS_F16) return launch_scan_dt<_Float16>(dim, nq, mode, a, grid, st);
-    if (dtype == ARTMIPS_BF16) return launch_scan_dt<__bf16>(dim, nq, mode, a, grid, st);
+static int launch_scan(int dtype, int dim, int nq, bool stage_lds, int mode, const ScanArgs& a, int grid,
+                       hipStream_t st) {
+    if (dtype == ARTMIPS_F16)
+        return stage_lds ? launch_scan_dt<_Float16, 1>(dim, nq, mode, a, grid, st)
+                         : launch_scan_dt<_Float16, 0>(dim, nq, mode, a, grid, st);
+    if (dtype == ARTMIPS_BF16)
+        return stage_lds ? launch_scan_dt<__bf16, 1>(dim, nq, mode, a, grid, st)
+                         : launch_scan_dt<__bf16, 0>(dim, nq, mode, a, grid, st);
     if (dtype == ARTMIPS_F32 && nq == 1) {
         // fp32 rows: 48 KiB stages, exact-f32 MFMA (1/16 of the f16 rate): one column group only
-        if (dim == 768) return launch_scan_t<float, 768, 3, 1, 2, 1>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<float, 128, 8, 1, 2, 1>(mode, a, grid, st);
+        if (dim == 768) return launch_scan_t<float, 768, 3, 1, 2, 1, 1>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<float, 128, 8, 1, 2, 1, 1>(mode, a, grid, st);
     }
-    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for storage_dtype=%d", dtype);
+    return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for storage_dtype=%d dim=%d nq=%d", dtype, dim, nq);
 }
 
 // column groups per pass the kernels are built for at this width
@@ -541,6 +550,7 @@ struct Plan {
     int cap;              // entries per candidate list
     long long n_tiles;
     int nq;               // column groups (of 64 queries) per scan pass
+    bool stage_lds;       // stage survivors in LDS (few per lane) instead of storing them directly
 };
 
 static int round_up_pow2(long long x) {
@@ -565,9 +575,9 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
     long long groups = std::max<long long>(1024, 8ll * k);
     long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
     // sample = n_tiles / sample_div.  A larger sample costs pass-0 time but tightens tau, and every
-    // survivor costs the main scan time too (profiles/r01_e_sample_sweep.txt): 1/64 of the rows is
-    // the measured optimum at k = 32..100, 1/16 at k = 1000.
-    long long sample_div = (k <= 128) ? 64 : (k <= 512) ? 32 : 16;
+    // survivor costs select time (and, without LDS staging, scan time): 1/128 of the rows is the
+    // measured optimum at k = 32..100, 1/16 at k = 1000 (profiles/r01_e_sample_sweep.txt, r01_j_*).
+    long long sample_div = (k <= 128) ? (nq == 1 ? 128 : 64) : (k <= 512) ? 32 : 16;
     if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
     long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
     p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
@@ -582,7 +592,11 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
         long long cap = round_up_pow2((long long)std::ceil(per_list * 8.0) + 16);
         cap *= cap_boost;
         p.cap = (int)std::min<long long>(cap, cap_max);
+        // LDS staging holds 8/nq survivors per lane and column group; it pays while a lane flushes
+        // at most a few times per launch (profiles/r01_j_lds_staging_ab.txt)
+        p.stage_lds = per_list <= 4.0 * (STAGING_BYTES / (SCAN_THREADS * nq * 8));
     } else {
+        p.stage_lds = false;
         p.grid0 = 0;
         p.n_sample = 0;
         p.sample_stride = 1;
@@ -626,7 +640,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     if (p.pass0) {
         a.n_work = p.n_sample;
         a.tile_stride = p.sample_stride;
-        int rc = launch_scan(h->dtype, h->dim, p.nq, MODE_GROUPMAX, a, p.grid0, st);
+        int rc = launch_scan(h->dtype, h->dim, p.nq, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
         size_t kth_lds = 8;
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
@@ -647,7 +661,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         s.ev_scan.push_back(e);
     }
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
-    int rc = launch_scan(h->dtype, h->dim, p.nq, MODE_FILTER, a, p.grid, st);
+    int rc = launch_scan(h->dtype, h->dim, p.nq, p.stage_lds, MODE_FILTER, a, p.grid, st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
 

@@ -36,6 +36,7 @@ constexpr int SCAN_THREADS = 256;
 constexpr int TILE_ROWS = 16;    // rows per LDS stage (one 16x16x32 MFMA row block)
 constexpr int SORT_MAX = 8192;   // 64-bit keys sorted in LDS by select/merge (64 KiB)
 constexpr int SEL_THREADS = 1024;
+constexpr int STAGING_BYTES = 16384;  // LDS behind the scan's ring: survivors staged per lane
 
 enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
 
@@ -310,7 +311,7 @@ __device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
 
 // Query q of the pass lives in column group j = q / 64, wave w = (q % 64) / 16, MFMA column r = q % 16.
 // List / counter / maximum of (workgroup b, group j, thread tid): index (b*NQ + j)*256 + tid.
-template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ>
+template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ, int STG = 1>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
     constexpr int ES = (int)sizeof(T);     // bytes per stored element
@@ -436,6 +437,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     int2* const my_list = (MODE == MODE_FILTER)
         ? a.lists + ((size_t)b * NQ * SCAN_THREADS + tid) * (size_t)a.cap : nullptr;
     const size_t list_stride = (size_t)SCAN_THREADS * (size_t)a.cap;  // between column groups
+    // Survivors are staged in LDS (SLOTS entries per lane and column group, behind the ring) and
+    // copied to the lane's list in HBM only when the staging is full and at the end of the launch.
+    // A global store inside the loop would sit in the vmcnt queue behind the DMAs in flight and make
+    // the counted wait of the next stage retire one DMA piece too many (~one stage period lost per
+    // store instruction, profiles/r01_e_sample_sweep.txt).
+    constexpr int SLOTS = STAGING_BYTES / (SCAN_THREADS * NQ * 8);
+    static_assert(SLOTS >= 1, "staging area too small");
+    int2* const stg = (int2*)(smem + NSTAGE * STAGE_BYTES);   // [NQ][SLOTS][256]
+    auto flush = [&](int j, int first, int last) {  // copy staged entries [first, last) to HBM
+        for (int e = first; e < last; ++e)
+            if (e < a.cap) my_list[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * SCAN_THREADS + tid];
+    };
 
     if (n_it > 0) {
         // prologue: NSTAGE-1 stages in flight
@@ -501,9 +514,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                             for (int i = 0; i < 4; ++i) {
                                 const long long row = row_base + i;
                                 if (acc[j][i] >= thr[j] && row < n_rows) {
-                                    if (cnt[j] < a.cap)
+                                    if (STG) {
+                                        const int slot_e = cnt[j] % SLOTS;
+                                        if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
+                                        stg[(j * SLOTS + slot_e) * SCAN_THREADS + tid] =
+                                            make_int2(__float_as_int(acc[j][i]), (int)row);
+                                    } else if (cnt[j] < a.cap) {
                                         my_list[j * list_stride + cnt[j]] =
                                             make_int2(__float_as_int(acc[j][i]), (int)row);
+                                    }
                                     ++cnt[j];
                                 }
                             }
@@ -521,6 +540,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
         wait_vmcnt<0>();
+    }
+    if (MODE == MODE_FILTER && STG) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            if (cnt[j] > 0) flush(j, ((cnt[j] - 1) / SLOTS) * SLOTS, cnt[j]);
     }
     // counters / maxima are stored query-major ([query][workgroup*4 + lane group]) so that the
     // selection kernels read the L values of a query as one contiguous run

@@ -20,17 +20,20 @@ shapes = [tuple(int(x) for x in s.split("x")) for s in sys.argv[1].split(",")]
 divs = [int(x) for x in sys.argv[2].split(",")]
 for nq, k in shapes:
     q = torch.randn((nq, 768), generator=g, device="cuda").half()
+    variants = os.environ.get("VARIANTS", "0").split(",")
     for d in divs:
         os.environ["ARTMIPS_SAMPLE_DIV"] = str(d)
-        tot, scan = [], []
-        for r in range(4):
-            eng.search(q, k)
-            info = eng.info()
-            if r:
-                tot.append(info["last_total_ms"])
-                scan.append(info["last_scan_ms"])
-        tot.sort()
-        scan.sort()
-        print("Q=%d k=%d div=%d: pipeline %.3f ms (scan %.3f)  cand/query %.0f retries %d -> %.0f q/s"
-              % (nq, k, d, tot[1], scan[1], info["last_candidates"] / nq, info["last_retries"], nq / tot[1] * 1e3),
-              flush=True)
+        res = {v: ([], []) for v in variants}
+        for r in range(6):
+            for v in variants:  # interleaved: same process, same device, same data
+                os.environ["ARTMIPS_SCAN_VARIANT"] = v
+                eng.search(q, k)
+                info = eng.info()
+                if r:
+                    res[v][0].append(info["last_total_ms"])
+                    res[v][1].append(info["last_scan_ms"])
+        for v in variants:
+            tot, scan = sorted(res[v][0]), sorted(res[v][1])
+            print("Q=%d k=%d div=%d variant %s: pipeline %.3f ms (scan median %.3f min %.3f)  cand/query %.0f -> %.0f q/s"
+                  % (nq, k, d, v, tot[2], scan[2], scan[0], info["last_candidates"] / nq, nq / tot[2] * 1e3),
+                  flush=True)
