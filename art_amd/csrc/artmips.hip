@@ -139,7 +139,7 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1, int STG = 1>
+template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1, int STG = 1, int NW = 4>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
     static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
@@ -147,21 +147,21 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
     if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ, STG>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ, STG, NW>;
         if (!attr_done[dev][0]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
             attr_done[dev][0] = true;
         }
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ, STG>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ, STG, NW>;
         if (!attr_done[dev][1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
             attr_done[dev][1] = true;
         }
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -179,7 +179,11 @@ static int scan_variant() {
 // stg: stage survivors in LDS (1, few survivors per lane: k <= 128) or store them straight to the
 // HBM lists (0, many survivors per lane: the staging would flush all the time)
 template <typename T, int STG>
-static int launch_scan_dt(int dim, int nq, int mode, const ScanArgs& a, int grid, hipStream_t st) {
+static int launch_scan_dt(int dim, int nq, int nw, int mode, const ScanArgs& a, int grid, hipStream_t st) {
+    if (dim == 768 && nw == 8) {
+        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2, 0, 8>(mode, a, grid, st);
+    }
+    if (nw != 4) return fail(ARTMIPS_ERR_UNSUPPORTED, "no %d-wave scan kernel for dim=%d nq=%d", nw, dim, nq);
     if (dim == 768) {
         if (nq == 1) {
             if (sizeof(T) == 2 && scan_variant() != 0) {
@@ -214,15 +218,15 @@ static int launch_scan_dt(int dim, int nq, int mode, const ScanArgs& a, int grid
 
 // Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
 // DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
-static int launch_scan(int dtype, int dim, int nq, bool stage_lds, int mode, const ScanArgs& a, int grid,
-                       hipStream_t st) {
+static int launch_scan(int dtype, int dim, int nq, int nw, bool stage_lds, int mode, const ScanArgs& a,
+                       int grid, hipStream_t st) {
     if (dtype == ARTMIPS_F16)
-        return stage_lds ? launch_scan_dt<_Float16, 1>(dim, nq, mode, a, grid, st)
-                         : launch_scan_dt<_Float16, 0>(dim, nq, mode, a, grid, st);
+        return stage_lds ? launch_scan_dt<_Float16, 1>(dim, nq, nw, mode, a, grid, st)
+                         : launch_scan_dt<_Float16, 0>(dim, nq, nw, mode, a, grid, st);
     if (dtype == ARTMIPS_BF16)
-        return stage_lds ? launch_scan_dt<__bf16, 1>(dim, nq, mode, a, grid, st)
-                         : launch_scan_dt<__bf16, 0>(dim, nq, mode, a, grid, st);
-    if (dtype == ARTMIPS_F32 && nq == 1) {
+        return stage_lds ? launch_scan_dt<__bf16, 1>(dim, nq, nw, mode, a, grid, st)
+                         : launch_scan_dt<__bf16, 0>(dim, nq, nw, mode, a, grid, st);
+    if (dtype == ARTMIPS_F32 && nq == 1 && nw == 4) {
         // fp32 rows: 48 KiB stages, exact-f32 MFMA (1/16 of the f16 rate): one column group only
         if (dim == 768) return launch_scan_t<float, 768, 3, 1, 2, 1, 1>(mode, a, grid, st);
         if (dim == 128) return launch_scan_t<float, 128, 8, 1, 2, 1, 1>(mode, a, grid, st);
@@ -549,7 +553,8 @@ struct Plan {
     int grid;             // blocks of the FILTER scan
     int cap;              // entries per candidate list
     long long n_tiles;
-    int nq;               // column groups (of 64 queries) per scan pass
+    int nq;               // column groups per scan pass
+    int nw;               // waves per scan workgroup (4 or 8); a column group is 16*nw queries
     bool stage_lds;       // stage survivors in LDS (few per lane) instead of storing them directly
 };
 
@@ -559,9 +564,10 @@ static int round_up_pow2(long long x) {
     return (int)std::min<long long>(p, 1ll << 30);
 }
 
-static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int nq) {
+static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int nq, int nw) {
     Plan p;
     p.nq = nq;
+    p.nw = nw;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     int grid_mult = 1;
     if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
@@ -594,7 +600,8 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
         p.cap = (int)std::min<long long>(cap, cap_max);
         // LDS staging holds 8/nq survivors per lane and column group; it pays while a lane flushes
         // at most a few times per launch (profiles/r01_j_lds_staging_ab.txt)
-        p.stage_lds = per_list <= 4.0 * (STAGING_BYTES / (SCAN_THREADS * nq * 8));
+        // (8 waves x 2 groups has no registers left for the staging bookkeeping: it would spill in the loop)
+    p.stage_lds = !(nw == 8 && nq == 2) && per_list <= 4.0 * (STAGING_BYTES / (nw * 64 * nq * 8));
     } else {
         p.stage_lds = false;
         p.grid0 = 0;
@@ -609,7 +616,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
 template <typename T>
 static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int dim, void* out,
                         int* status_to_clear, hipStream_t st) {
-    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(64 * (q_tile / QGROUP)), dim3(256), 0, st, q, q_dtype,
+    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(q_tile), dim3(256), 0, st, q, q_dtype,
                        q_count, q_tile, dim, (T*)out, status_to_clear);
 }
 
@@ -618,7 +625,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
                         int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
                         long long out_row0, hipStream_t st, int tile_index) {
     const Generation& gen = s.live;
-    const int qt = p.nq * QGROUP;
+    const int qt = p.nq * p.nw * 16;
     int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;
     if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
     else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
@@ -640,7 +647,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     if (p.pass0) {
         a.n_work = p.n_sample;
         a.tile_stride = p.sample_stride;
-        int rc = launch_scan(h->dtype, h->dim, p.nq, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
+        int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
         size_t kth_lds = 8;
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
@@ -655,13 +662,14 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
 
     a.n_work = p.n_tiles;
     a.tile_stride = 1;
+    if (const char* e = getenv("ARTMIPS_ABLATE")) a.ablate = atoi(e);  // diagnostics: wrong results
     while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         s.ev_scan.push_back(e);
     }
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
-    int rc = launch_scan(h->dtype, h->dim, p.nq, p.stage_lds, MODE_FILTER, a, p.grid, st);
+    int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid, st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
 
@@ -672,6 +680,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     sa.cap = p.cap;
     sa.scan_grid = p.grid;
     sa.nq = p.nq;
+    sa.threads = p.nw * 64;
     sa.ids = gen.ids;
     sa.keys_ws = (u64*)s.keys.p;
     sa.keys_stride = (long long)(s.keys.bytes / 8 / (size_t)qt);
@@ -714,19 +723,35 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     DeviceGuard g(s.dev);
     if (gen.n_rows == 0) return fail(ARTMIPS_ERR_STATE, "shard %d is empty", c.slot);
     const size_t q_row_bytes = (size_t)h->dim * elem_size(c.q_dtype);
-    // up to 256 queries share one sweep over the rows (4 column groups of 64)
-    int nq = (int)std::min<int64_t>((c.n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
+    // Up to 256 queries share one sweep over the rows.  Shapes (waves x column groups):
+    //   4 x 1..3  64..192 queries, one wave per SIMD (4 x 1 is the HBM-bound training step);
+    //   8 x 2     256 queries as two groups of 128: two waves per SIMD overlap one wave's DMA issue,
+    //             LDS waits and filter with the other's MFMAs (MFMA busy 45 % -> 54 %; the chip gives
+    //             most of it back as clock, 2.00 -> 1.75 GHz: profiles/r01_m_clock_ablation.json);
+    //   4 x 4     256 queries where no 8-wave kernel is built (dim != 768, fp32 storage).
+    int nw = 4, nq;
+    const bool wide_ok = (h->dim == 768 && h->dtype != ARTMIPS_F32);
+    int want_nw = (wide_ok && c.n_q > 3 * QGROUP) ? 8 : 4;
+    if (const char* e = getenv("ARTMIPS_NW")) want_nw = (atoi(e) == 8 && wide_ok) ? 8 : 4;
+    if (want_nw == 8) {
+        nw = 8;
+        nq = 2;
+    } else {
+        nq = (int)std::min<int64_t>((c.n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
+    }
     if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
-    const int QT = nq * QGROUP;
+    if (nw == 8 && nq != 2) nw = 4;  // only the 8 x 2 shape is built
+    const int QT = nq * nw * 16;
+    const int NT = nw * 64;
     c.t_begin = std::chrono::steady_clock::now();
-    Plan p = make_plan(s, gen.n_rows, c.k, h->cap_boost, nq);
+    Plan p = make_plan(s, gen.n_rows, c.k, h->cap_boost, nq, nw);
     int rc = 0;
     if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
     if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
     if ((rc = ensure(s.status, 64))) return rc;
-    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * SCAN_THREADS * 4))) return rc;
-    if ((rc = ensure(s.counts, (size_t)p.grid * nq * SCAN_THREADS * 4))) return rc;
-    const size_t list_entries = (size_t)p.grid * nq * SCAN_THREADS * (size_t)p.cap;
+    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * NT * 4))) return rc;
+    if ((rc = ensure(s.counts, (size_t)p.grid * nq * NT * 4))) return rc;
+    const size_t list_entries = (size_t)p.grid * nq * NT * (size_t)p.cap;
     if ((rc = ensure(s.lists, list_entries * 8))) return rc;
     // global key scratch: worst case every list of a query is full
     const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;

@@ -160,6 +160,8 @@ struct ScanArgs {
     int* counts;          // FILTER: [64*NQ][grid*4] candidates seen by each lane (may exceed cap)
     int cap;
     float* gmax;          // GROUPMAX: [64*NQ][grid*4] running max of each lane
+    int ablate;           // diagnostics only (ARTMIPS_ABLATE, results are then meaningless):
+                          // 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
 };
 
 // LDS image of a stage (16 rows).  Two layouts are built; both are bank-conflict free for the
@@ -254,9 +256,34 @@ __device__ __forceinline__ void mg_mfma_chunk(f32x4* acc, const V* af, const V (
         mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, I + 1, V>(acc, af, bq);
     }
 }
-template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int C, typename V>
+// The refill of the ring (this wave's PPW pieces of the stage NSTAGE-1 ahead) rides inside the
+// compute phase: piece pp is issued after chunk FIRST + pp*SPAN/PPW.  With 8 waves the two waves
+// that share a SIMD (w and w+4) use different halves of the phase (FIRST = 0 / NCH/2), so one
+// wave's DMA issue (60-185 cycles a piece, MI355X_MICROARCH.md) overlaps the other's MFMAs.
+struct MgDma {
+    const void* tile;        // uniform: first byte of the tile to fetch
+    const uint32_t* lane_off;// [PPW] byte offset of this lane's chunk inside the tile
+    uint32_t dst0;           // uniform: LDS address of this wave's first piece
+    bool on;                 // uniform: false = the caller issued the stage itself
+    bool late;               // uniform: this wave issues in the second half of the phase
+};
+template <int AUX, int PPW, int NCH, int NW, int C, int PP>
+__device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
+    if constexpr (PP < PPW) {
+        constexpr int SPAN = (NW == 8) ? NCH / 2 : NCH;
+        constexpr int AT = (PP * SPAN) / PPW;          // chunk (inside the span) after which piece PP goes
+        if constexpr (NW == 8) {
+            if constexpr (C == AT) { if (d.on && !d.late) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+            if constexpr (C == AT + SPAN) { if (d.on && d.late) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+        } else {
+            if constexpr (C == AT) { if (d.on) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+        }
+        mg_dma_after_chunk<AUX, PPW, NCH, NW, C, PP + 1>(d);
+    }
+}
+template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int AUX, int PPW, int NW, int C, typename V>
 __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq)[KSTEPS],
-                                           const uint32_t (&base)[4]) {
+                                           const uint32_t (&base)[4], const MgDma& d) {
     if constexpr (C < NCH) {
         if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
         if constexpr (C + 1 < NCH) {
@@ -266,7 +293,8 @@ __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq
             mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
         }
         mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
-        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, C + 1, V>(acc, af, bq, base);
+        mg_dma_after_chunk<AUX, PPW, NCH, NW, C, 0>(d);
+        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, C + 1, V>(acc, af, bq, base, d);
     }
 }
 // MFMA results must not be read by ordinary VALU code before the pipeline has written them:
@@ -283,20 +311,20 @@ __device__ __forceinline__ void mg_settle(f32x4* acc) {
 // Load the query operand.  Fragment f = j*KSTEPS + s goes to a VGPR tuple (ordinary load) or, on the
 // asm path for f >= VB, straight into an AGPR tuple (global_load can target AGPRs; an ordinary load
 // followed by a copy would be re-materialised by hipcc inside the loop).
-template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int LAYOUT, int F, typename V>
+template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int LAYOUT, int QG, int F, typename V>
 __device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, int g) {
     if constexpr (F < NQ * KSTEPS) {
         constexpr int j = F / KSTEPS, s = F % KSTEPS;
         const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
         constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
         constexpr int DIMQ = KSTEPS * 4 * EPC;              // row width in elements
-        const T* src = qrow0 + (size_t)j * QGROUP * DIMQ + chunk * EPC;
+        const T* src = qrow0 + (size_t)j * QG * DIMQ + chunk * EPC;
         if constexpr (ASM_PATH && F >= VB) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[j][s]) : "v"(src) : "memory");
         } else {
             bq[j][s] = *(const V*)src;
         }
-        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, F + 1, V>(bq, qrow0, g);
+        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, QG, F + 1, V>(bq, qrow0, g);
     }
 }
 template <int NQ, int KSTEPS, int VB, bool ASM_PATH, int F, typename V>
@@ -309,10 +337,14 @@ __device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
     }
 }
 
-// Query q of the pass lives in column group j = q / 64, wave w = (q % 64) / 16, MFMA column r = q % 16.
-// List / counter / maximum of (workgroup b, group j, thread tid): index (b*NQ + j)*256 + tid.
-template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ, int STG = 1>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
+// A workgroup has NW waves (4 or 8); QG = 16*NW queries form a column group, NT = 64*NW threads.
+// Query q of the pass lives in column group j = q / QG, wave w = (q % QG) / 16, MFMA column r = q % 16.
+// List of (workgroup b, group j, thread tid): index (b*NQ + j)*NT + tid.
+// NW = 8 puts two waves on every SIMD: while one issues its LDS-DMA pieces or waits for LDS, the
+// other keeps the matrix pipe busy (profiles/r01_k_pmc_sq_counters.json: with one wave per SIMD the
+// pipe idles 55 % of the time at 256 queries per sweep).
+template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ, int STG = 1, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
     constexpr int ES = (int)sizeof(T);     // bytes per stored element
     constexpr int EPC = 16 / ES;           // elements per 16-byte chunk
@@ -320,11 +352,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     constexpr int KSTEPS = ROWB / 64;      // k-steps per row: 4 lane groups x one 16-byte chunk each
     constexpr int CPR = ROWB / 16;         // 16-byte chunks per row
     constexpr int PIECES = TILE_ROWS * ROWB / 1024;  // 1-KiB pieces per 16-row stage
-    constexpr int PPW = PIECES / 4;        // pieces each of the 4 waves issues per stage
+    constexpr int NT = NW * 64;            // threads per workgroup
+    constexpr int QG = NW * 16;            // queries per column group
+    constexpr int PPW = PIECES / NW;       // pieces each wave issues per stage
     constexpr int STAGE_BYTES = TILE_ROWS * ROWB;
     constexpr int MPF = (ES == 4) ? 4 : 1; // MFMA instructions per fragment
     static_assert(DIM % 128 == 0, "DIM must be a multiple of 128");
-    static_assert(PIECES % 4 == 0, "pieces must split evenly over 4 waves");
+    static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
     static_assert((NSTAGE - 2) * PPW <= 63, "vmcnt field is 6 bits");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -334,13 +368,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15;  // MFMA row (row operand) / column (query operand) of this lane
     const int g = lane >> 4;  // MFMA k-group of this lane
-    const bool wave_active = (w * 16) < a.q_count;   // group 0 of this wave has a real query
+    const bool wave_active = (w * 16) < a.q_count && !(a.ablate & 4);   // group 0 of this wave has a real query
     // row-operand fragments are read in NCH chunks when the query operand leaves too few registers
-    constexpr int NCH = (KSTEPS >= 24) ? ((NQ >= 4) ? 6 : 4) : 1;
+    constexpr int NCH = (KSTEPS >= 24) ? ((NW == 8) ? ((NQ >= 2) ? 12 : 8) : (NQ >= 4) ? 6 : 4) : 1;
     constexpr int CH = KSTEPS / NCH;
     static_assert(KSTEPS % NCH == 0, "k-steps must split evenly into chunks");
     // query fragments j*KSTEPS+s < VB live in VGPRs, the others in AGPRs (asm path, NQ >= 2)
-    constexpr int VB = (NQ <= 3) ? KSTEPS : KSTEPS + (KSTEPS * 3) / 8;
+    constexpr int VB = (NW == 8) ? NQ * KSTEPS : (NQ <= 3) ? KSTEPS : KSTEPS + (KSTEPS * 3) / 8;
     static_assert((NQ * KSTEPS - VB) * 4 <= 252 || NQ == 1, "query operand does not fit the AGPR file");
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -352,9 +386,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     V bq[NQ][KSTEPS];
     float thr[NQ];
     constexpr bool ASM_PATH = (NQ >= 2 && LAYOUT == 1);
-    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
+    constexpr bool INLINE_DMA = (NW == 8);   // refill issued between the MFMA chunks (mg_compute)
+    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, QG, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) thr[j] = (MODE == MODE_FILTER) ? a.thr[j * QGROUP + w * 16 + r] : 0.0f;
+    for (int j = 0; j < NQ; ++j)
+        thr[j] = (MODE == MODE_FILTER) ? (a.ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
     // drain these loads before any LDS-DMA is in flight, so that hipcc never has a reason to put a
     // vmcnt(0) inside the streaming loop (the asm loads into AGPRs are not counted by hipcc at all)
     wait_vmcnt<0>();
@@ -435,19 +471,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     for (int j = 0; j < NQ; ++j) { cnt[j] = 0; gm[j] = -INFINITY; }
     // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
     int2* const my_list = (MODE == MODE_FILTER)
-        ? a.lists + ((size_t)b * NQ * SCAN_THREADS + tid) * (size_t)a.cap : nullptr;
-    const size_t list_stride = (size_t)SCAN_THREADS * (size_t)a.cap;  // between column groups
+        ? a.lists + ((size_t)b * NQ * NT + tid) * (size_t)a.cap : nullptr;
+    const size_t list_stride = (size_t)NT * (size_t)a.cap;  // between column groups
     // Survivors are staged in LDS (SLOTS entries per lane and column group, behind the ring) and
     // copied to the lane's list in HBM only when the staging is full and at the end of the launch.
     // A global store inside the loop would sit in the vmcnt queue behind the DMAs in flight and make
     // the counted wait of the next stage retire one DMA piece too many (~one stage period lost per
     // store instruction, profiles/r01_e_sample_sweep.txt).
-    constexpr int SLOTS = STAGING_BYTES / (SCAN_THREADS * NQ * 8);
+    constexpr int SLOTS = STAGING_BYTES / (NT * NQ * 8);
     static_assert(SLOTS >= 1, "staging area too small");
-    int2* const stg = (int2*)(smem + NSTAGE * STAGE_BYTES);   // [NQ][SLOTS][256]
+    int2* const stg = (int2*)(smem + NSTAGE * STAGE_BYTES);   // [NQ][SLOTS][NT]
     auto flush = [&](int j, int first, int last) {  // copy staged entries [first, last) to HBM
         for (int e = first; e < last; ++e)
-            if (e < a.cap) my_list[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * SCAN_THREADS + tid];
+            if (e < a.cap) my_list[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * NT + tid];
     };
 
     if (n_it > 0) {
@@ -460,9 +496,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
         for (long long it = 0; it < n_it; ++it) {
             // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
             wait_vmcnt<(NSTAGE - 2) * PPW>();
-            asm volatile("s_barrier" ::: "memory");
-            // every wave has finished reading the slot consumed in the previous iteration: refill it
-            issue_stage(it + NSTAGE - 1, fill_slot);
+            if (!(a.ablate & 2)) asm volatile("s_barrier" ::: "memory");
+            // every wave has finished reading the slot consumed in the previous iteration: refill it.
+            // On the multi-group path a working wave spreads the refill over its compute phase
+            // (mg_compute) when the tile is whole; otherwise all pieces go out here.
+            MgDma dma;
+            dma.on = false;
+            if constexpr (ASM_PATH && INLINE_DMA) {
+                long long wk = b + (it + NSTAGE - 1) * grid;
+                if (wk > last_work) wk = last_work;
+                const long long row0 = wk * stride * TILE_ROWS;
+                dma.on = wave_active && (row0 + TILE_ROWS <= n_rows) && !(a.ablate & 1);
+                dma.tile = (const char*)rows + row0 * ROWB;
+                dma.lane_off = lane_off;
+                dma.dst0 = lds_base + (uint32_t)(fill_slot * STAGE_BYTES + w * PPW * 1024);
+                dma.late = (w >= NW / 2);
+            }
+            if (!dma.on && !(a.ablate & 1)) issue_stage(it + NSTAGE - 1, fill_slot);
             fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
 
             if (wave_active) {
@@ -500,7 +550,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                     uint32_t base[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) base[m] = lds_base + (uint32_t)(slot * STAGE_BYTES + rd_off[m]);
-                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, 0, V>(acc, af, bq, base);
+                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma);
                     mg_settle<NQ, 0>(acc);
                 }
                 // acc[j][i] = score(row = tile*16 + g*4 + i, query = j*64 + w*16 + r)
@@ -517,7 +567,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
                                     if (STG) {
                                         const int slot_e = cnt[j] % SLOTS;
                                         if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
-                                        stg[(j * SLOTS + slot_e) * SCAN_THREADS + tid] =
+                                        stg[(j * SLOTS + slot_e) * NT + tid] =
                                             make_int2(__float_as_int(acc[j][i]), (int)row);
                                     } else if (cnt[j] < a.cap) {
                                         my_list[j * list_stride + cnt[j]] =
@@ -550,7 +600,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // selection kernels read the L values of a query as one contiguous run
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const size_t o = (size_t)(j * QGROUP + w * 16 + r) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
+        const size_t o = (size_t)(j * QG + w * 16 + r) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
         if (MODE == MODE_FILTER) a.counts[o] = cnt[j];
         else a.gmax[o] = gm[j];
     }
@@ -833,6 +883,7 @@ struct SelectArgs {
     int cap;
     int scan_grid;          // blocks of the FILTER scan (<= 1024)
     int nq;                 // column groups of the FILTER scan
+    int threads;            // threads per workgroup of the FILTER scan (256 or 512)
     const int32_t* ids;     // [n_rows] passage id of each local row
     u64* keys_ws;           // [q_tile][keys_stride] global key scratch for M > SORT_MAX
     long long keys_stride;
@@ -856,7 +907,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     const int tid = threadIdx.x;
     const int L = a.scan_grid * 4;  // candidate lists of this query
     auto list_of = [&](int li) -> size_t {
-        return ((size_t)(li >> 2) * a.nq + (q >> 6)) * SCAN_THREADS + ((q & 63) >> 4) * 64 + (li & 3) * 16 + (q & 15);
+        const int qg = a.threads >> 2;  // queries per column group
+        return ((size_t)(li >> 2) * a.nq + q / qg) * a.threads + ((q % qg) >> 4) * 64 + (li & 3) * 16 + (q & 15);
     };
     // ---- exclusive offsets of the lists: thread t owns lists [t*per, t*per+per)
     const int nt = blockDim.x;

@@ -21,6 +21,7 @@ p.add_argument("--rounds", type=int, default=6)
 p.add_argument("--queries", type=int, default=64)
 p.add_argument("--topk", type=int, default=32)
 p.add_argument("--nq-sweep", action="store_true", help="variants are values of ARTMIPS_MAX_NQ (1..4)")
+p.add_argument("--shape-sweep", action="store_true", help="variants are NW:NQ pairs (ARTMIPS_NW, ARTMIPS_MAX_NQ)")
 args = p.parse_args()
 
 eng = MipsEngine(768, torch.float16, [0])
@@ -34,17 +35,24 @@ totals = {v: [] for v in variants}
 ref = None
 for rnd in range(args.rounds + 1):
     for v in variants:
-        os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
-        os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
+        if not args.shape_sweep:
+            os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
+            os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
         if args.nq_sweep:
             os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ["ARTMIPS_MAX_NQ"] = v
+        if args.shape_sweep:
+            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
+            os.environ["ARTMIPS_NW"], os.environ["ARTMIPS_MAX_NQ"] = v.split(":")[:2]
+            os.environ["ARTMIPS_ABLATE"] = v.split(":")[2] if v.count(":") > 1 else "0"
         s, i = eng.search(q, args.topk, score_dtype=torch.float32)
         info = eng.info()
         if rnd > 0:
             times[v].append(info["last_scan_ms"])
             totals[v].append(info["last_total_ms"])
-        if ref is None:
+        if os.environ.get("ARTMIPS_ABLATE", "0") != "0":
+            pass  # ablated runs compute nothing meaningful
+        elif ref is None:
             ref = (s.clone(), i.clone())
         else:
             same = bool((i == ref[1]).all())
