@@ -27,6 +27,10 @@ SYMBOLS = (
     "artmips_search",
     "artmips_search_local",
     "artmips_merge",
+    "artmips_packed_words",
+    "artmips_search_local_async",
+    "artmips_merge_packed",
+    "artmips_grow_lists",
     "artmips_info",
     "artmips_last_error",
     "artmips_version",
@@ -90,6 +94,14 @@ def _load():
     lib.artmips_search_local.restype = i32
     lib.artmips_merge.argtypes = [i32, vp, vp, i32, i64, i32, vp, i32, vp, vp]
     lib.artmips_merge.restype = i32
+    lib.artmips_packed_words.argtypes = [i64, i32]
+    lib.artmips_packed_words.restype = i64
+    lib.artmips_search_local_async.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+    lib.artmips_search_local_async.restype = i32
+    lib.artmips_merge_packed.argtypes = [i32, vp, i32, i64, i32, vp, i32, vp, vp, vp]
+    lib.artmips_merge_packed.restype = i32
+    lib.artmips_grow_lists.argtypes = [vp]
+    lib.artmips_grow_lists.restype = i32
     lib.artmips_info.argtypes = [vp, ctypes.POINTER(ArtmipsInfo)]
     lib.artmips_info.restype = i32
     lib.artmips_last_error.argtypes = []

@@ -101,6 +101,8 @@ struct artmips {
     int64_t last_candidates = 0;
     int cap_boost = 1;  // sticky multiplier learnt from overflow retries
     bool stats_pending = false;
+    bool stats_async = false;          // the pending stats belong to artmips_search_local_async
+    hipStream_t stats_stream = nullptr;
     double host_enqueue_us = 0, host_sync_us = 0;
     int stats_slot = 0, stats_tiles = 0;
 };
@@ -564,7 +566,7 @@ static int round_up_pow2(long long x) {
     return (int)std::min<long long>(p, 1ll << 30);
 }
 
-static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int nq, int nw) {
+static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, int cap_boost, int nq, int nw) {
     Plan p;
     p.nq = nq;
     p.nw = nw;
@@ -580,10 +582,17 @@ static Plan make_plan(const Shard& s, int64_t n_rows, int k, int cap_boost, int 
     // of about 1/128 of the rows, but never more than 1/4 of them.
     long long groups = std::max<long long>(1024, 8ll * k);
     long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
-    // sample = n_tiles / sample_div.  A larger sample costs pass-0 time but tightens tau, and every
-    // survivor costs select time (and, without LDS staging, scan time): 1/128 of the rows is the
-    // measured optimum at k = 32..100, 1/16 at k = 1000 (profiles/r01_e_sample_sweep.txt, r01_j_*).
-    long long sample_div = (k <= 128) ? (nq == 1 ? 128 : 64) : (k <= 512) ? 32 : 16;
+    // sample = n_tiles / sample_div.  Pass 0 costs scan_time / sample_div; every survivor of the
+    // filter costs scan time (a wave that keeps one holds its workgroup at the next barrier) and
+    // select time, and the expected survivors per query are k * sample_div whatever the shard size.
+    // Minimising the sum gives sample_div = sqrt(c * n_tiles / (k * column groups per wave)) with
+    // c = 0.45 for 1536-byte rows, fitted on shards of 2.6M..21M rows at k = 32 and 100
+    // (profiles/r01_o_sample_by_size.txt): 128 at 21M rows and k = 32, 48 on a 1/8 shard.
+    const double row_scale = (double)row_bytes / 1536.0;
+    const double groups_per_wave = (double)nq * (double)nw / 4.0;
+    long long sample_div = (long long)std::llround(
+        std::sqrt(0.45 * row_scale * (double)p.n_tiles / ((double)k * groups_per_wave)));
+    sample_div = std::min<long long>(128, std::max<long long>(16, sample_div));
     if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
     long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
     p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
@@ -744,7 +753,7 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     const int QT = nq * nw * 16;
     const int NT = nw * 64;
     c.t_begin = std::chrono::steady_clock::now();
-    Plan p = make_plan(s, gen.n_rows, c.k, h->cap_boost, nq, nw);
+    Plan p = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq, nw);
     int rc = 0;
     if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
     if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
@@ -790,6 +799,7 @@ static int shard_complete(artmips* h, ShardCall& c, bool* overflow) {
         h->stats_slot = c.slot;
         h->stats_tiles = c.n_tiles_q;
         h->stats_pending = true;  // event times are read when artmips_info asks for them
+        h->stats_async = false;
         unsigned long long n = 0;
         memcpy(&n, s.status_host + 2, 8);
         h->last_candidates = (int64_t)n;
@@ -852,7 +862,8 @@ static std::mutex g_merge_mutex;
 
 static int run_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
                      int k, void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
-                     DevBuf* keys, DevBuf* status_buf) {
+                     DevBuf* keys, DevBuf* status_buf, long long list_stride = 0,
+                     const int* status_in = nullptr, long long status_stride = 0, int* flag_out = nullptr) {
     DeviceGuard g(device);
     MergeArgs m;
     memset(&m, 0, sizeof(m));
@@ -864,6 +875,10 @@ static int run_merge(int device, const float* scores, const int32_t* ids, int n_
     m.out_scores = out_scores;
     m.score_dtype = score_dtype;
     m.out_ids = out_ids;
+    m.list_stride = list_stride ? list_stride : (long long)n_q * k;
+    m.status_in = status_in;
+    m.status_stride = status_stride;
+    m.flag_out = flag_out;
     const long long total = (long long)n_lists * k;
     int rc = 0;
     if (status_buf->bytes < 64) {
@@ -899,6 +914,63 @@ extern "C" int artmips_merge(int device, const float* scores, const int32_t* ids
     MergeScratch& ms = g_merge_scratch[device];
     return run_merge(device, scores, ids, n_lists, n_q, k, out_scores, score_dtype, out_ids,
                      (hipStream_t)stream, &ms.keys, &ms.status);
+}
+
+extern "C" int64_t artmips_packed_words(int64_t n_q, int k) {
+    return 2 * n_q * (int64_t)k + ARTMIPS_PACK_TAIL;
+}
+
+extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_dev, int q_dtype,
+                                          int64_t n_q, int k, int32_t* out_packed, void* stream) {
+    int rc = check_search_args(h, q_dev, q_dtype, n_q, k, out_packed, out_packed);
+    if (rc) return rc;
+    if (slot < 0 || slot >= h->n_dev) return fail(ARTMIPS_ERR_ARG, "slot %d out of range", slot);
+    const int64_t n_local = h->sh[slot].live.n_rows;
+    if (k > ARTMIPS_MAX_K && n_local > SORT_MAX)
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k, ARTMIPS_MAX_K,
+                    (long long)n_local);
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    ShardCall c{slot, q_dev, q_dtype, n_q, k, out_packed, ARTMIPS_F32, out_packed + n_q * (int64_t)k,
+                (hipStream_t)stream, true};
+    if ((rc = shard_enqueue(h, c))) return rc;
+    Shard& s = h->sh[slot];
+    DeviceGuard g(s.dev);
+    // the shard's status words travel with the candidates: whoever merges them sees the overflow bit
+    HIP_TRY(hipMemcpyAsync(out_packed + 2 * n_q * (int64_t)k, s.status.p, ARTMIPS_PACK_TAIL * 4,
+                           hipMemcpyDeviceToDevice, c.st));
+    h->host_enqueue_us = std::chrono::duration<double, std::micro>(c.t_enq - c.t_begin).count();
+    h->host_sync_us = 0.0;
+    h->stats_slot = slot;
+    h->stats_tiles = c.n_tiles_q;
+    h->stats_pending = true;
+    h->stats_async = true;
+    h->stats_stream = c.st;
+    h->last_retries = 0;
+    return 0;
+}
+
+extern "C" int artmips_grow_lists(artmips_t* h) {
+    if (!h) return fail(ARTMIPS_ERR_ARG, "NULL handle");
+    if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
+    h->cap_boost *= 8;
+    return 0;
+}
+
+extern "C" int artmips_merge_packed(int device, const int32_t* packed, int n_lists, int64_t n_q, int k,
+                                    void* out_scores, int score_dtype, int32_t* out_ids,
+                                    int32_t* out_flag, void* stream) {
+    if (!packed || !out_scores || !out_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (n_lists < 1 || n_q < 1 || k < 1) return fail(ARTMIPS_ERR_ARG, "n_lists, n_q and k must be >= 1");
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
+    if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
+    const long long plane = (long long)n_q * k;
+    const long long stride = 2 * plane + ARTMIPS_PACK_TAIL;
+    std::lock_guard<std::mutex> lock(g_merge_mutex);
+    MergeScratch& ms = g_merge_scratch[device];
+    return run_merge(device, (const float*)packed, packed + plane, n_lists, n_q, k, out_scores, score_dtype,
+                     out_ids, (hipStream_t)stream, &ms.keys, &ms.status, stride,
+                     out_flag ? packed + 2 * plane : nullptr, stride, out_flag);
 }
 
 extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
@@ -992,6 +1064,13 @@ extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
     if (h->stats_pending) {
         Shard& s = h->sh[h->stats_slot];
         DeviceGuard g(s.dev);
+        if (h->stats_async) {  // nobody has waited for that pipeline on the library's behalf yet
+            HIP_TRY(hipStreamSynchronize(h->stats_stream));
+            unsigned long long n = 0;
+            memcpy(&n, s.status_host + 2, 8);
+            h->last_candidates = (int64_t)n;
+            h->stats_async = false;
+        }
         float ms = 0, total = 0;
         for (int t = 0; t < h->stats_tiles; ++t) {
             float x = 0;

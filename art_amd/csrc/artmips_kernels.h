@@ -988,6 +988,10 @@ struct MergeArgs {
     int score_dtype;
     int32_t* out_ids;
     int* status;
+    long long list_stride;  // elements between the [n_q][k] planes of consecutive lists
+    const int* status_in;   // optional: one status word per list (status_in[l * status_stride])
+    long long status_stride;
+    int* flag_out;          // optional: OR of the lists' status words
 };
 
 __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
@@ -1000,6 +1004,11 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     const int tid = threadIdx.x;
     const int total = a.n_lists * a.k;
     const bool in_lds = (total <= SORT_MAX);
+    if (a.flag_out && q == 0 && tid == 0) {
+        int f = 0;
+        for (int l = 0; l < a.n_lists; ++l) f |= a.status_in[(size_t)l * a.status_stride];
+        a.flag_out[0] = f;
+    }
     u64* gk = a.keys_ws ? a.keys_ws + (size_t)q * a.keys_stride : nullptr;
     if (!in_lds && (gk == nullptr || (long long)total > a.keys_stride)) {
         if (tid == 0) atomicOr(a.status, 2);
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     u64* dst = in_lds ? skeys : gk;
     for (int i = tid; i < total; i += blockDim.x) {
         const int l = i / a.k, j = i - l * a.k;
-        const size_t src = ((size_t)l * a.n_q + q) * a.k + j;
+        const size_t src = (size_t)l * a.list_stride + (size_t)q * a.k + j;
         const int32_t id = a.ids[src];
         if (id == 0x7fffffff) continue;
         const u64 key = make_key(a.scores[src], id);

@@ -48,9 +48,67 @@ def spmd_search(local_search, merge, queries, top_k, group=None):
     return merge(all_scores, all_ids)
 
 
-def engine_spmd_search(engine, queries, top_k, score_dtype=torch.float16, group=None):
-    """spmd_search bound to a one-shard MipsEngine."""
-    from .engine import MipsEngine
+class SpmdSearcher(object):
+    """The SPMD step of a one-shard MipsEngine with one collective and one host wait:
 
-    return spmd_search(lambda q, k: engine.search_local(0, q, k),
-                       lambda s, i: MipsEngine.merge(s, i, score_dtype), queries, top_k, group)
+        search_local_async (no wait) -> all_gather_into_tensor of the packed list -> merge_packed
+        -> read ONE int32 flag (OR of every rank's overflow bit, identical on all ranks).
+
+    Everything up to the flag read is only enqueued, so the launch latency of the collective and of
+    the merge hides behind the scan.  If some rank's candidate lists overflowed (rare: the lists
+    are sized 8x the expectation) every rank sees it in the flag, grows its lists and repeats the
+    step, so the ranks never disagree about the number of collectives.
+    Buffers are cached per (Q, k): the steady state allocates only the two result tensors."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self._bufs = {}
+        self.last_retries = 0
+
+    def _buffers(self, n_q, top_k, world, dev):
+        key = (n_q, top_k, world)
+        b = self._bufs.get(key)
+        if b is None:
+            from .engine import MipsEngine
+
+            words = MipsEngine.packed_words(n_q, top_k)
+            gathered = torch.empty((world, words), dtype=torch.int32, device=dev)
+            local = gathered[0] if world == 1 else torch.empty((words,), dtype=torch.int32, device=dev)
+            b = (local, gathered, torch.zeros((1,), dtype=torch.int32, device=dev))
+            if len(self._bufs) >= 8:
+                self._bufs.clear()
+            self._bufs[key] = b
+        return b
+
+    def search(self, queries, top_k, score_dtype=torch.float16):
+        from .engine import MipsEngine
+
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        n_q = queries.shape[0]
+        local, gathered, flag = self._buffers(n_q, int(top_k), world, queries.device)
+        self.last_retries = 0
+        while True:
+            self.engine.search_local_async(0, queries, top_k, local)
+            if world > 1:
+                if dist.get_backend(self.group) == "nccl":
+                    dist.all_gather_into_tensor(gathered, local, group=self.group)
+                else:  # gloo (tests): the rows of `gathered` are contiguous views
+                    dist.all_gather(list(gathered.unbind(0)), local, group=self.group)
+            out = MipsEngine.merge_packed(gathered, n_q, top_k, score_dtype, flag)
+            status = int(flag.item())  # the step's only host wait
+            if status & 2:
+                raise RuntimeError("artmips: internal key scratch too small on some rank")
+            if not (status & 1):
+                return out
+            self.engine.grow_lists()
+            self.last_retries += 1
+
+
+def engine_spmd_search(engine, queries, top_k, score_dtype=torch.float16, group=None):
+    """SPMD search of a one-shard MipsEngine (one SpmdSearcher per engine, cached on it)."""
+    searcher = getattr(engine, "_spmd_searcher", None)
+    if searcher is None or searcher.group is not group:
+        searcher = SpmdSearcher(engine, group)
+        engine._spmd_searcher = searcher
+    return searcher.search(queries, top_k, score_dtype)

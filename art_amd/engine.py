@@ -209,6 +209,53 @@ class MipsEngine(object):
                                     ctypes.c_void_p(out_i.data_ptr()), _stream_ptr(dev)))
         return out_s, out_i
 
+    # ---- SPMD step without a host round trip (include/artmips.h, "the SPMD step ...") ----------
+    @staticmethod
+    def packed_words(n_q, top_k):
+        return int(lib.artmips_packed_words(int(n_q), int(top_k)))
+
+    def search_local_async(self, slot, queries, top_k, out_packed):
+        """Enqueue the local top-k of shard `slot` into out_packed (int32 [packed_words(Q, k)]:
+        score bits | ids | status tail) on torch's current stream.  Does not wait, does not retry."""
+        top_k = int(top_k)
+        if top_k < 1:
+            raise ValueError("top_k must be >= 1")
+        q = self._check_queries(queries, self.devices[slot])
+        if (out_packed.dtype != torch.int32 or not out_packed.is_cuda or not out_packed.is_contiguous()
+                or out_packed.device != q.device
+                or out_packed.numel() != self.packed_words(q.shape[0], top_k)):
+            raise ValueError("out_packed must be a contiguous CUDA int32 tensor of packed_words(Q, k) words")
+        with torch.cuda.device(q.device):
+            check(lib.artmips_search_local_async(self._h, int(slot), ctypes.c_void_p(q.data_ptr()),
+                                                 _abi_dtype(q.dtype), q.shape[0], top_k,
+                                                 ctypes.c_void_p(out_packed.data_ptr()),
+                                                 _stream_ptr(q.device)))
+        # the library reads q after this returns: keep it alive until the stream gets there
+        q.record_stream(torch.cuda.current_stream(q.device))
+
+    @staticmethod
+    def merge_packed(packed, n_q, top_k, score_dtype=torch.float16, out_flag=None):
+        """Merge [G, packed_words(Q, k)] packed lists; out_flag (CUDA int32 [1]) receives the OR of
+        their status words.  Asynchronous."""
+        if packed.dim() != 2 or packed.dtype != torch.int32 or not packed.is_cuda or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous CUDA int32 tensor [G, words]")
+        if packed.shape[1] != MipsEngine.packed_words(n_q, top_k):
+            raise ValueError("packed lists have %d words, expected %d"
+                             % (packed.shape[1], MipsEngine.packed_words(n_q, top_k)))
+        dev = packed.device
+        out_s = torch.empty((n_q, top_k), dtype=score_dtype, device=dev)
+        out_i = torch.empty((n_q, top_k), dtype=torch.int32, device=dev)
+        flag_ptr = ctypes.c_void_p(out_flag.data_ptr()) if out_flag is not None else ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            check(lib.artmips_merge_packed(dev.index, ctypes.c_void_p(packed.data_ptr()), packed.shape[0],
+                                           int(n_q), int(top_k), ctypes.c_void_p(out_s.data_ptr()),
+                                           _abi_dtype(score_dtype), ctypes.c_void_p(out_i.data_ptr()),
+                                           flag_ptr, _stream_ptr(dev)))
+        return out_s, out_i
+
+    def grow_lists(self):
+        check(lib.artmips_grow_lists(self._h))
+
     def info(self):
         out = _lib.ArtmipsInfo()
         check(lib.artmips_info(self._h, ctypes.byref(out)))

@@ -19,7 +19,7 @@
  *   - all device work is enqueued on / ordered against `stream`; the search entry
  *     points synchronise that stream before they return (they must read a
  *     device status word to guarantee exactness);
- *     artmips_merge does not.
+ *     artmips_merge, artmips_merge_packed and artmips_search_local_async do not.
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
  *   - passage ids are int32 (the reference returns int32: art_index.py:297).
  *   - top-k order: score descending, ties broken by LOWER passage id
@@ -55,6 +55,7 @@ enum {
 
 #define ARTMIPS_MAX_DEVICES 16
 #define ARTMIPS_MAX_K 2048 /* for indexes larger than ARTMIPS_SORT_MAX rows */
+#define ARTMIPS_PACK_TAIL 4 /* int32 status words behind a packed candidate list */
 
 typedef struct artmips_info {
     int32_t n_dev;                              /* shards (one per device slot)           */
@@ -148,6 +149,37 @@ int artmips_search_local(artmips_t* h, int slot, const void* q_dev, int q_dtype,
  * (art_index.py:283-294) with a merge over k*n_lists candidates per query. */
 int artmips_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
                   int k, void* out_scores, int score_dtype, int32_t* out_ids, void* stream);
+
+/* ---- the SPMD step without a host round trip in the middle -------------------------
+ * art_model.py:345-365 (gather queries, search on one rank, two broadcasts) becomes,
+ * on every rank:  artmips_search_local_async -> ONE all-gather of the packed buffer
+ * (RCCL, torch.distributed.all_gather_into_tensor) -> artmips_merge_packed -> read
+ * one int32 flag.  Nothing waits for the host between the three steps, so their
+ * launch latencies hide behind the scan.
+ *
+ * A packed candidate list is artmips_packed_words(n_q, k) int32 words:
+ *   [n_q*k] fp32 score bits | [n_q*k] int32 passage ids | ARTMIPS_PACK_TAIL status words
+ * (word 0: bit 0 = a candidate list overflowed, the result may be inexact;
+ *  bit 1 = internal scratch too small). */
+int64_t artmips_packed_words(int64_t n_q, int k);
+
+/* artmips_search_local (art_index.py:278-280,294) without the wait and without the
+ * overflow retry: enqueues the shard's pipeline on `stream` and returns.  The
+ * overflow bit travels in the status tail of out_packed instead. */
+int artmips_search_local_async(artmips_t* h, int slot, const void* q_dev, int q_dtype, int64_t n_q,
+                               int k, int32_t* out_packed, void* stream);
+
+/* artmips_merge over n_lists packed lists laid out back to back (what the all-gather
+ * leaves).  If out_flag (device int32) is given it receives the OR of the lists'
+ * status words: every rank reads the same value, so all ranks agree on a retry.
+ * Asynchronous on `stream`. */
+int artmips_merge_packed(int device, const int32_t* packed, int n_lists, int64_t n_q, int k,
+                         void* out_scores, int score_dtype, int32_t* out_ids, int32_t* out_flag,
+                         void* stream);
+
+/* After a flag with bit 0 set: make the candidate lists of this handle 8x larger
+ * (what artmips_search does internally before it retries), then repeat the step. */
+int artmips_grow_lists(artmips_t* h);
 
 /* Shard sizes, memory and the HIP-event timings of the last search. */
 int artmips_info(artmips_t* h, artmips_info_t* out);

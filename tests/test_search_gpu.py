@@ -296,3 +296,58 @@ def test_argument_errors(gu):
     with pytest.raises(ValueError):
         eng.search(torch.zeros(2, 768, dtype=torch.int32, device="cuda"), 3)
     eng.close()
+
+
+def test_async_local_search_and_packed_merge(gu):
+    """The no-round-trip SPMD step on one GPU: four shards searched with search_local_async into
+    one [4, words] buffer (what all_gather_into_tensor leaves), merged by merge_packed."""
+    from art_amd.engine import MipsEngine
+    rows, queries, ids = _random_case(6000, 9, 768, seed=23)
+    k = 40
+    bounds = orc.shard_bounds(6000, 4)
+    q = torch.from_numpy(queries).cuda()
+    words = MipsEngine.packed_words(9, k)
+    assert words == 2 * 9 * k + 4
+    gathered = torch.empty((4, words), dtype=torch.int32, device="cuda")
+    engines = []
+    for g, (lo, hi) in enumerate(bounds):
+        eng = gu.build_engine(rows[lo:hi], ids[lo:hi])
+        eng.search_local_async(0, q, k, gathered[g])
+        engines.append(eng)
+    flag = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    s, i = MipsEngine.merge_packed(gathered, 9, k, torch.float32, flag)
+    assert int(flag.item()) == 0
+    assert int(gathered[:, 2 * 9 * k].abs().max().item()) == 0
+    orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64),
+                   ids, k, rel_tol=REL_TOL)
+    # and it is the same answer as the blocking pair search_local + merge
+    sl = torch.stack([e.search_local(0, q, k)[0] for e in engines])
+    il = torch.stack([e.search_local(0, q, k)[1] for e in engines])
+    s2, i2 = MipsEngine.merge(sl, il, torch.float32)
+    assert torch.equal(i, i2) and torch.equal(s, s2)
+    for e in engines:
+        e.close()
+
+
+def test_spmd_searcher_overflow_retry_is_exact(gu):
+    """SpmdSearcher reads the overflow bit from the merged flag and repeats the step with larger
+    lists (same adversarial input as test_overflow_retry_is_exact)."""
+    from art_amd.distributed import SpmdSearcher
+    n, dim, k = 131072, 768, 8
+    rng = np.random.Generator(np.random.PCG64(11))
+    rows = (rng.standard_normal((n, dim)) * 0.05).astype(np.float16)
+    queries = rng.standard_normal((2, dim)).astype(np.float16)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    tiles = np.arange(n // 16)
+    for t in tiles[tiles % 8 == 0]:
+        rows[t * 16:(t + 1) * 16] = 0
+    eng = gu.build_engine(rows, ids)
+    searcher = SpmdSearcher(eng)
+    s, i = searcher.search(torch.from_numpy(queries).cuda(), k, score_dtype=torch.float32)
+    assert searcher.last_retries >= 1, "this input is meant to overflow the candidate lists"
+    orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64),
+                   ids, k, rel_tol=REL_TOL)
+    # a second call starts with the grown lists: no retry, same answer
+    s2, i2 = searcher.search(torch.from_numpy(queries).cuda(), k, score_dtype=torch.float32)
+    assert searcher.last_retries == 0 and torch.equal(i, i2)
+    eng.close()
