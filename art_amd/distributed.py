@@ -60,9 +60,10 @@ class SpmdSearcher(object):
     step, so the ranks never disagree about the number of collectives.
     Buffers are cached per (Q, k): the steady state allocates only the two result tensors."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, always_gather=False):
         self.engine = engine
         self.group = group
+        self.always_gather = always_gather  # run the collective even with one rank (measurements)
         self._bufs = {}
         self.last_retries = 0
 
@@ -74,7 +75,8 @@ class SpmdSearcher(object):
 
             words = MipsEngine.packed_words(n_q, top_k)
             gathered = torch.empty((world, words), dtype=torch.int32, device=dev)
-            local = gathered[0] if world == 1 else torch.empty((words,), dtype=torch.int32, device=dev)
+            alias = (world == 1 and not self.always_gather)
+            local = gathered[0] if alias else torch.empty((words,), dtype=torch.int32, device=dev)
             b = (local, gathered, torch.zeros((1,), dtype=torch.int32, device=dev))
             if len(self._bufs) >= 8:
                 self._bufs.clear()
@@ -90,7 +92,7 @@ class SpmdSearcher(object):
         self.last_retries = 0
         while True:
             self.engine.search_local_async(0, queries, top_k, local)
-            if world > 1:
+            if world > 1 or self.always_gather:
                 if dist.get_backend(self.group) == "nccl":
                     dist.all_gather_into_tensor(gathered, local, group=self.group)
                 else:  # gloo (tests): the rows of `gathered` are contiguous views

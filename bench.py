@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--topk", type=int, default=32)
     p.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-spmd", action="store_true",
+                   help="run the multi-rank step (async local search, RCCL all-gather, packed merge) even with one rank")
     p.add_argument("--cpu-rows", type=int, default=1000000, help="rows of the CPU baseline sample (config 1)")
     return p.parse_args()
 
@@ -100,10 +102,14 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    spmd = world > 1 or args.force_spmd
+    if spmd:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from art_amd.distributed import engine_spmd_search, shard_bounds
+    from art_amd.distributed import SpmdSearcher, shard_bounds
     from art_amd.engine import MipsEngine
 
     storage = torch.float16 if args.dtype == "f16" else torch.bfloat16
@@ -115,10 +121,12 @@ def main():
     gq.manual_seed(4321)
     queries = torch.randn((args.queries, DIM), generator=gq, device=dev, dtype=torch.float32).to(storage)
 
+    searcher = SpmdSearcher(engine, always_gather=True) if spmd else None
+
     def step():
-        if world == 1:
+        if not spmd:
             return engine.search(queries, args.topk)
-        return engine_spmd_search(engine, queries, args.topk)
+        return searcher.search(queries, args.topk)
 
     def fence():
         torch.cuda.synchronize()
@@ -199,13 +207,13 @@ def main():
                 "kernel_ms_avg": scan_avg_ms,
             },
             "candidates_per_query": info["last_candidates"] / max(1, args.queries),
-            "overflow_retries": info["last_retries"],
+            "overflow_retries": searcher.last_retries if spmd else info["last_retries"],
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rows, 64, 32)
         print(json.dumps(line), flush=True)
     engine.close()
-    if world > 1:
+    if spmd:
         dist.destroy_process_group()
 
 
