@@ -21,6 +21,7 @@ p.add_argument("--rounds", type=int, default=6)
 p.add_argument("--queries", type=int, default=64)
 p.add_argument("--topk", type=int, default=32)
 p.add_argument("--nq-sweep", action="store_true", help="variants are values of ARTMIPS_MAX_NQ (1..4)")
+p.add_argument("--env", default=None, help="variants are values of this environment variable")
 p.add_argument("--shape-sweep", action="store_true", help="variants are NW:NQ pairs (ARTMIPS_NW, ARTMIPS_MAX_NQ)")
 args = p.parse_args()
 
@@ -35,12 +36,15 @@ totals = {v: [] for v in variants}
 ref = None
 for rnd in range(args.rounds + 1):
     for v in variants:
-        if not args.shape_sweep:
+        if not args.shape_sweep and not args.env:
             os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
             os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
         if args.nq_sweep:
             os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ["ARTMIPS_MAX_NQ"] = v
+        if args.env:
+            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
+            os.environ[args.env] = v
         if args.shape_sweep:
             os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ["ARTMIPS_NW"], os.environ["ARTMIPS_MAX_NQ"] = v.split(":")[:2]
