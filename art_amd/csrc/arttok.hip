@@ -1,0 +1,171 @@
+// libarttok.so — evidence token store in HBM + batched id -> tokens gather (include/arttok.h).
+// gfx950 only.  One wave per fetched item; HBM-bound byte work, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/arttok.h"
+
+static thread_local char g_tok_err[512] = "";
+
+static int tok_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_tok_err, sizeof(g_tok_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define TOK_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return tok_fail(ARTTOK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                               \
+    } while (0)
+
+struct TokDeviceGuard {
+    int prev = -1;
+    explicit TokDeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~TokDeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct arttok {
+    int device = 0;
+    int elem_bytes = 0;
+    int64_t n_items = 0, n_tokens = 0;
+    void* tokens = nullptr;     // [n_tokens] elements
+    int64_t* offsets = nullptr; // [n_items] ELEMENT offset of every item
+    int32_t* sizes = nullptr;   // [n_items]
+};
+
+// One wave (64 lanes) per output row; rows are grid-strided.  Lanes read consecutive tokens of the
+// item (coalesced) and write consecutive int32 of the padded row.
+template <typename E>
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict__ tokens,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ sizes,
+                                                            int64_t n_items, const int32_t* __restrict__ ids,
+                                                            int64_t n, int32_t id_base, int max_len,
+                                                            int32_t pad, int32_t* __restrict__ out_tokens,
+                                                            int32_t* __restrict__ out_lens) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = wave; i < n; i += n_waves) {
+        const int64_t item = (int64_t)ids[i] - id_base;
+        int32_t* row = out_tokens + i * max_len;
+        int len = -1;
+        const E* src = nullptr;
+        if (item >= 0 && item < n_items) {
+            len = sizes[item] < max_len ? sizes[item] : max_len;
+            src = tokens + offsets[item];
+        }
+        for (int t = lane; t < max_len; t += 64) row[t] = (t < len) ? (int32_t)src[t] : pad;
+        if (lane == 0) out_lens[i] = len;
+    }
+}
+
+extern "C" const char* arttok_last_error(void) { return g_tok_err; }
+
+extern "C" int arttok_create(int device, const void* tokens_host, int64_t n_tokens, int elem_bytes,
+                             const int64_t* pointers, const int32_t* sizes, int64_t n_items,
+                             arttok_t** out) {
+    if (!out || !pointers || !sizes || (!tokens_host && n_tokens > 0))
+        return tok_fail(ARTTOK_ERR_ARG, "NULL argument");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8)
+        return tok_fail(ARTTOK_ERR_ARG, "elem_bytes must be 1, 2, 4 or 8 (got %d)", elem_bytes);
+    if (n_items < 1 || n_tokens < 0) return tok_fail(ARTTOK_ERR_ARG, "empty dataset");
+    int n_dev = 0;
+    TOK_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return tok_fail(ARTTOK_ERR_ARG, "device %d of %d", device, n_dev);
+    // byte pointers -> element offsets, with the bounds check the kernel relies on
+    int64_t* off = new (std::nothrow) int64_t[n_items];
+    if (!off) return tok_fail(ARTTOK_ERR_NOMEM, "host allocation failed");
+    for (int64_t i = 0; i < n_items; ++i) {
+        const int64_t p = pointers[i];
+        if (p < 0 || p % elem_bytes != 0 || sizes[i] < 0 || p / elem_bytes + sizes[i] > n_tokens) {
+            delete[] off;
+            return tok_fail(ARTTOK_ERR_ARG, "item %lld (pointer %lld, size %d) lies outside the %lld tokens",
+                            (long long)i, (long long)p, sizes[i], (long long)n_tokens);
+        }
+        off[i] = p / elem_bytes;
+    }
+    TokDeviceGuard g(device);
+    arttok* h = new (std::nothrow) arttok;
+    if (!h) {
+        delete[] off;
+        return tok_fail(ARTTOK_ERR_NOMEM, "host allocation failed");
+    }
+    h->device = device;
+    h->elem_bytes = elem_bytes;
+    h->n_items = n_items;
+    h->n_tokens = n_tokens;
+    const size_t tok_bytes = (size_t)(n_tokens > 0 ? n_tokens : 1) * elem_bytes;
+    hipError_t e = hipMalloc(&h->tokens, tok_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->offsets, (size_t)n_items * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->sizes, (size_t)n_items * 4);
+    if (e == hipSuccess && n_tokens > 0)
+        e = hipMemcpy(h->tokens, tokens_host, (size_t)n_tokens * elem_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->offsets, off, (size_t)n_items * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->sizes, sizes, (size_t)n_items * 4, hipMemcpyHostToDevice);
+    delete[] off;
+    if (e != hipSuccess) {
+        arttok_destroy(h);
+        return tok_fail(e == hipErrorOutOfMemory ? ARTTOK_ERR_NOMEM : ARTTOK_ERR_HIP, "upload failed: %s",
+                        hipGetErrorString(e));
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void arttok_destroy(arttok_t* h) {
+    if (!h) return;
+    TokDeviceGuard g(h->device);
+    if (h->tokens) (void)hipFree(h->tokens);
+    if (h->offsets) (void)hipFree(h->offsets);
+    if (h->sizes) (void)hipFree(h->sizes);
+    delete h;
+}
+
+extern "C" int arttok_gather(arttok_t* h, const int32_t* ids_dev, int64_t n, int32_t id_base, int max_len,
+                             int32_t pad, int32_t* out_tokens, int32_t* out_lens, void* stream) {
+    if (!h || !ids_dev || !out_tokens || !out_lens) return tok_fail(ARTTOK_ERR_ARG, "NULL argument");
+    if (n < 1) return tok_fail(ARTTOK_ERR_ARG, "n must be >= 1");
+    if (max_len < 1 || max_len > (1 << 20)) return tok_fail(ARTTOK_ERR_ARG, "max_len %d out of range", max_len);
+    TokDeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int waves_per_block = 4;
+    const int64_t want = (n + waves_per_block - 1) / waves_per_block;
+    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+#define LAUNCH(E)                                                                                      \
+    hipLaunchKernelGGL(gather_tokens_kernel<E>, dim3(grid), dim3(64 * waves_per_block), 0, st,         \
+                       (const E*)h->tokens, (const int64_t*)h->offsets, (const int32_t*)h->sizes,      \
+                       h->n_items, ids_dev, n, id_base, max_len, pad, out_tokens, out_lens)
+    switch (h->elem_bytes) {
+        case 1: LAUNCH(uint8_t); break;
+        case 2: LAUNCH(uint16_t); break;
+        case 4: LAUNCH(int32_t); break;
+        default: LAUNCH(int64_t); break;
+    }
+#undef LAUNCH
+    TOK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int arttok_info(arttok_t* h, int64_t* n_items, int64_t* n_tokens, int64_t* device_bytes) {
+    if (!h) return tok_fail(ARTTOK_ERR_ARG, "NULL handle");
+    if (n_items) *n_items = h->n_items;
+    if (n_tokens) *n_tokens = h->n_tokens;
+    if (device_bytes) *device_bytes = h->n_tokens * h->elem_bytes + h->n_items * 12;
+    return 0;
+}

@@ -14,4 +14,5 @@ if [ "${1:-}" = "--asm" ]; then
 else
   hipcc $flags -o "$out/libartmips.so" "$here/artmips.hip"
 fi
-echo "built $out/libartmips.so"
+hipcc $flags -o "$out/libarttok.so" "$here/arttok.hip"
+echo "built $out/libartmips.so $out/libarttok.so"

@@ -49,3 +49,51 @@ def test_spmd_two_ranks_one_gpu(tmp_path, world):
         for r in range(world):
             np.testing.assert_array_equal(np.load(tmp_path / ("i%d_%d.npy" % (k, r))), fx["ids_k%d" % k])
             np.testing.assert_array_equal(np.load(tmp_path / ("s%d_%d.npy" % (k, r))), fx["scores_k%d" % k])
+
+
+def _caller_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd.caller import spmd_evaluate_search, spmd_get_topk
+        from art_amd.distributed import SpmdSearcher, shard_bounds
+        from art_amd.engine import MipsEngine
+        torch.cuda.set_device(0)
+        fx = np.load(os.path.join(GOLDEN, "fx_small_fp16.npz"))
+        lo, hi = shard_bounds(fx["rows"].shape[0], world)[rank]
+        eng = MipsEngine(768, torch.float16, [0])
+        eng.build(fx["rows"][lo:hi], fx["ids"][lo:hi])
+        searcher = SpmdSearcher(eng)
+        q = torch.from_numpy(fx["queries"]).cuda()
+        b = q.shape[0] // world
+        # art_model.py:345-365 without the broadcasts: every rank ends with ITS rows
+        d, t = spmd_get_topk(searcher, q[rank * b:(rank + 1) * b], 32)
+        assert d.dtype == torch.float16 and t.dtype == torch.int32 and d.is_cuda
+        np.save(os.path.join(out_dir, "t%d.npy" % rank), t.cpu().numpy())
+        np.save(os.path.join(out_dir, "d%d.npy" % rank), d.float().cpu().numpy())
+        # evaluate.py:140-177 with ragged per-rank query counts, one call and chunked
+        sizes = [5, 3] if world == 2 else [3, 0, 5]
+        off = sum(sizes[:rank])
+        d1, t1, allsizes = spmd_evaluate_search(searcher, q[off:off + sizes[rank]], 100)
+        d2, t2, _ = spmd_evaluate_search(searcher, q[off:off + sizes[rank]], 100, shard_size=3)
+        assert allsizes == sizes and torch.equal(t1, t2) and torch.equal(d1, d2)
+        np.save(os.path.join(out_dir, "e%d.npy" % rank), t1.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_caller_protocol_spmd_on_gpu(tmp_path, world):
+    port = 29200 + (os.getpid() % 300) + world
+    mp.spawn(_caller_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    fx = np.load(os.path.join(GOLDEN, "fx_small_fp16.npz"))
+    b = fx["queries"].shape[0] // world
+    sizes = [5, 3] if world == 2 else [3, 0, 5]
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / ("t%d.npy" % r)), fx["ids_k32"][r * b:(r + 1) * b])
+        np.testing.assert_allclose(np.load(tmp_path / ("d%d.npy" % r)), fx["scores_k32"][r * b:(r + 1) * b],
+                                   rtol=2e-3)  # fp16 output rounding
+        off = sum(sizes[:r])
+        np.testing.assert_array_equal(np.load(tmp_path / ("e%d.npy" % r)), fx["ids_k100"][off:off + sizes[r]])
