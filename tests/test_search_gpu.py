@@ -351,3 +351,21 @@ def test_spmd_searcher_overflow_retry_is_exact(gu):
     s2, i2 = searcher.search(torch.from_numpy(queries).cuda(), k, score_dtype=torch.float32)
     assert searcher.last_retries == 0 and torch.equal(i, i2)
     eng.close()
+
+
+@pytest.mark.parametrize("n,q,k", [
+    (60000, 300, 50),     # 8 waves x 2 groups (256 queries) + a 44-query remainder, bf16 kernels
+    (120000, 513, 1000),  # three sweeps, k = 1000: direct list writes, radix select in global memory
+])
+def test_bf16_large_batch_shapes(gu, n, q, k):
+    rng = np.random.Generator(np.random.PCG64(n + q))
+    rows = (rng.standard_normal((n, 768)) * 0.05).astype(np.float32)
+    queries = rng.standard_normal((q, 768)).astype(np.float32)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids, storage=torch.bfloat16)
+    s, i = gu.search_np(eng, queries, k, q_dtype=torch.bfloat16)
+    n_diff = orc.check_topk(s, i, orc.to_storage(queries, "bf16"), orc.to_storage(rows, "bf16"), ids, k,
+                            rel_tol=REL_TOL)
+    assert n_diff <= max(2, (q * k) // 500)
+    assert eng.info()["last_retries"] == 0
+    eng.close()
