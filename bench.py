@@ -42,6 +42,11 @@ def parse():
     p.add_argument("--force-spmd", action="store_true",
                    help="run the multi-rank step (async local search, RCCL all-gather, packed merge) even with one rank")
     p.add_argument("--cpu-rows", type=int, default=1000000, help="rows of the CPU baseline sample (config 1)")
+    p.add_argument("--settle-seconds", type=float, default=8.0,
+                   help="GPU idle time between building the index and the warm-up steps: for some seconds "
+                        "after tens of GB of VRAM were released (e.g. by the process that ran before this "
+                        "one) the driver's background work takes ~4%% of the HBM bandwidth "
+                        "(profiles/r01_r_xcd_tile_order_ab.txt); at N=1 the CPU baseline runs in that time")
     return p.parse_args()
 
 
@@ -134,6 +139,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed: CPU baseline (rank 0, N=1) and the settle time, before any timed GPU work
+    t_built = time.perf_counter()
+    cpu_line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(args.cpu_rows, 64, 32)
+    left = args.settle_seconds - (time.perf_counter() - t_built)
+    if left > 0:
+        time.sleep(left)
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -209,8 +223,8 @@ def main():
             "candidates_per_query": info["last_candidates"] / max(1, args.queries),
             "overflow_retries": searcher.last_retries if spmd else info["last_retries"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_rows, 64, 32)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
     engine.close()
     if spmd:
