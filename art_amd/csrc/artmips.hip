@@ -114,8 +114,7 @@ static int ensure(DevBuf& b, size_t bytes) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
-    // grow geometrically so that repeated small increases do not reallocate every call
-    size_t want = bytes;
+    size_t want = bytes;  // callers size for the plan's worst case, so growth is rare (hipFree syncs)
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         b.p = nullptr;
@@ -141,7 +140,7 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIM, int NSTAGE, int LAYOUT, int AUX, int NQ = 1, int STG = 1, int NW = 4>
+template <typename T, int DIM, int NSTAGE, int AUX, int NQ = 1, int STG = 1, int NW = 4>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
     static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
@@ -149,7 +148,7 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
     if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, LAYOUT, AUX, NQ, STG, NW>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, AUX, NQ, STG, NW>;
         if (!attr_done[dev][0]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -157,7 +156,7 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, LAYOUT, AUX, NQ, STG, NW>;
+        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW>;
         if (!attr_done[dev][1]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
@@ -169,57 +168,37 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     return 0;
 }
 
-// ARTMIPS_SCAN_VARIANT selects an experimental build of the 768-wide f16 scan (tools/scan_sweep.py);
-// unset or 0 is the shipped configuration.
-static int scan_variant() {
-    const char* v = getenv("ARTMIPS_SCAN_VARIANT");
-    return v ? atoi(v) : 0;
-}
-
-// Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
-// DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
+// Non-temporal DMA loads (AUX = 2: the rows are read exactly once per call,
+// profiles/r01_b_scan_sweep.txt).
 // stg: stage survivors in LDS (1, few survivors per lane: k <= 128) or store them straight to the
 // HBM lists (0, many survivors per lane: the staging would flush all the time)
 template <typename T, int STG>
 static int launch_scan_dt(int dim, int nq, int nw, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dim == 768 && nw == 8) {
-        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2, 0, 8>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 768, 6, 2, 2, 0, 8>(mode, a, grid, st);
     }
     if (nw != 4) return fail(ARTMIPS_ERR_UNSUPPORTED, "no %d-wave scan kernel for dim=%d nq=%d", nw, dim, nq);
     if (dim == 768) {
         if (nq == 1) {
-            if (sizeof(T) == 2 && scan_variant() != 0) {
-                switch (scan_variant()) {  // experimental builds for tools/scan_sweep.py, sample_sweep.py
-                    case 1: return launch_scan_t<T, 768, 6, 0, 2>(mode, a, grid, st);
-                    case 2: return launch_scan_t<T, 768, 6, 1, 0>(mode, a, grid, st);
-                    case 3: return launch_scan_t<T, 768, 6, 0, 0>(mode, a, grid, st);
-                    case 4: return launch_scan_t<T, 768, 3, 1, 2>(mode, a, grid, st);
-                    case 5: return launch_scan_t<T, 768, 6, 1, 2, 1, 0>(mode, a, grid, st);
-                    case 6: return launch_scan_t<T, 768, 5, 1, 2, 1, 1>(mode, a, grid, st);
-                    default: break;
-                }
-            }
-            return launch_scan_t<T, 768, 6, 1, 2, 1, STG>(mode, a, grid, st);
+            return launch_scan_t<T, 768, 6, 2, 1, STG>(mode, a, grid, st);
         }
-        if (nq == 2) return launch_scan_t<T, 768, 6, 1, 2, 2, STG>(mode, a, grid, st);
-        if (nq == 3) return launch_scan_t<T, 768, 6, 1, 2, 3, STG>(mode, a, grid, st);
-        if (nq == 4) return launch_scan_t<T, 768, 6, 1, 2, 4, STG>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 768, 6, 2, 2, STG>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 768, 6, 2, 3, STG>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 768, 6, 2, 4, STG>(mode, a, grid, st);
     }
     if (dim == 1024) {
-        if (nq == 1) return launch_scan_t<T, 1024, 4, 1, 2, 1, STG>(mode, a, grid, st);
-        if (nq == 2) return launch_scan_t<T, 1024, 4, 1, 2, 2, STG>(mode, a, grid, st);
+        if (nq == 1) return launch_scan_t<T, 1024, 4, 2, 1, STG>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 1024, 4, 2, 2, STG>(mode, a, grid, st);
     }
     if (dim == 128) {
-        if (nq == 1) return launch_scan_t<T, 128, 8, 1, 2, 1, STG>(mode, a, grid, st);
-        if (nq == 2) return launch_scan_t<T, 128, 8, 1, 2, 2, STG>(mode, a, grid, st);
-        if (nq == 3) return launch_scan_t<T, 128, 8, 1, 2, 3, STG>(mode, a, grid, st);
-        if (nq == 4) return launch_scan_t<T, 128, 8, 1, 2, 4, STG>(mode, a, grid, st);
+        if (nq == 1) return launch_scan_t<T, 128, 8, 2, 1, STG>(mode, a, grid, st);
+        if (nq == 2) return launch_scan_t<T, 128, 8, 2, 2, STG>(mode, a, grid, st);
+        if (nq == 3) return launch_scan_t<T, 128, 8, 2, 3, STG>(mode, a, grid, st);
+        if (nq == 4) return launch_scan_t<T, 128, 8, 2, 4, STG>(mode, a, grid, st);
     }
     return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for dim=%d nq=%d", dim, nq);
 }
 
-// Shipped configuration: LAYOUT 1 (1-KiB contiguous DMA pieces, XOR-swizzled rows), non-temporal
-// DMA loads (aux = 2: the rows are read exactly once per call, profiles/r01_b_scan_sweep.txt).
 static int launch_scan(int dtype, int dim, int nq, int nw, bool stage_lds, int mode, const ScanArgs& a,
                        int grid, hipStream_t st) {
     if (dtype == ARTMIPS_F16)
@@ -230,8 +209,8 @@ static int launch_scan(int dtype, int dim, int nq, int nw, bool stage_lds, int m
                          : launch_scan_dt<__bf16, 0>(dim, nq, nw, mode, a, grid, st);
     if (dtype == ARTMIPS_F32 && nq == 1 && nw == 4) {
         // fp32 rows: 48 KiB stages, exact-f32 MFMA (1/16 of the f16 rate): one column group only
-        if (dim == 768) return launch_scan_t<float, 768, 3, 1, 2, 1, 1>(mode, a, grid, st);
-        if (dim == 128) return launch_scan_t<float, 128, 8, 1, 2, 1, 1>(mode, a, grid, st);
+        if (dim == 768) return launch_scan_t<float, 768, 3, 2, 1, 1>(mode, a, grid, st);
+        if (dim == 128) return launch_scan_t<float, 128, 8, 2, 1, 1>(mode, a, grid, st);
     }
     return fail(ARTMIPS_ERR_UNSUPPORTED, "no scan kernel for storage_dtype=%d dim=%d nq=%d", dtype, dim, nq);
 }

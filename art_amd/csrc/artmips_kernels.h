@@ -164,18 +164,12 @@ struct ScanArgs {
                           // 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
 };
 
-// LDS image of a stage (16 rows).  Two layouts are built; both are bank-conflict free for the
-// ds_read_b128 of the MFMA row operand and both rely on the fact that a dot product may sum its
-// k in any order as long as the row operand and the query operand agree on it.
-//
-// LAYOUT 0 ("8x128"): a DMA wave-instruction fetches 8 rows x 128 B.  kappa(g,e) is the 16-byte
-//   chunk (0..7) of a 128-byte column block that lane group g = lane>>4 multiplies in k-step half e.
-// LAYOUT 1 ("linear"): the stage is the 16 rows as they lie in memory (row-major, contiguous), cut
-//   into 1-KiB pieces; a DMA wave-instruction fetches 1 KiB of consecutive addresses.  The low four
-//   bits of every 16-byte chunk index are XORed with the row number, which spreads the 16 rows of a
-//   column over the 16 bank slots.  Lane group g multiplies chunk 4s+g in k-step s (natural order).
-__device__ __forceinline__ int kappa(int g, int e) { return 4 * (g & 1) + 2 * e + (g >> 1); }
-
+// LDS image of a stage (16 rows): the rows as they lie in memory (row-major, contiguous), cut into
+// 1-KiB pieces; a DMA wave-instruction fetches 1 KiB of consecutive addresses.  The low four bits of
+// every 16-byte chunk index are XORed with the row number, which spreads the 16 rows of a column over
+// the 16 bank slots (conflict-free ds_read_b128, profiles/r01_k_pmc_sq_counters.json).  Lane group g
+// multiplies chunk 4s+g in k-step s.  (An "8 rows x 128 B per piece" image was measured too and was
+// no faster: profiles/r01_b_scan_sweep.txt.)
 template <int AUX> __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
@@ -311,11 +305,11 @@ __device__ __forceinline__ void mg_settle(f32x4* acc) {
 // Load the query operand.  Fragment f = j*KSTEPS + s goes to a VGPR tuple (ordinary load) or, on the
 // asm path for f >= VB, straight into an AGPR tuple (global_load can target AGPRs; an ordinary load
 // followed by a copy would be re-materialised by hipcc inside the loop).
-template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int LAYOUT, int QG, int F, typename V>
+template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int QG, int F, typename V>
 __device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, int g) {
     if constexpr (F < NQ * KSTEPS) {
         constexpr int j = F / KSTEPS, s = F % KSTEPS;
-        const int chunk = (LAYOUT == 0) ? (8 * (s >> 1) + kappa(g, s & 1)) : (4 * s + g);
+        const int chunk = 4 * s + g;
         constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
         constexpr int DIMQ = KSTEPS * 4 * EPC;              // row width in elements
         const T* src = qrow0 + (size_t)j * QG * DIMQ + chunk * EPC;
@@ -324,7 +318,7 @@ __device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, in
         } else {
             bq[j][s] = *(const V*)src;
         }
-        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, QG, F + 1, V>(bq, qrow0, g);
+        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, F + 1, V>(bq, qrow0, g);
     }
 }
 template <int NQ, int KSTEPS, int VB, bool ASM_PATH, int F, typename V>
@@ -343,7 +337,7 @@ __device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
 // NW = 8 puts two waves on every SIMD: while one issues its LDS-DMA pieces or waits for LDS, the
 // other keeps the matrix pipe busy (profiles/r01_k_pmc_sq_counters.json: with one wave per SIMD the
 // pipe idles 55 % of the time at 256 queries per sweep).
-template <typename T, int DIM, int NSTAGE, int MODE, int LAYOUT, int AUX, int NQ, int STG = 1, int NW = 4>
+template <typename T, int DIM, int NSTAGE, int MODE, int AUX, int NQ, int STG = 1, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
     constexpr int ES = (int)sizeof(T);     // bytes per stored element
@@ -385,9 +379,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // ---- query operand: KSTEPS fragments of 8 elements, resident in registers for the whole launch
     V bq[NQ][KSTEPS];
     float thr[NQ];
-    constexpr bool ASM_PATH = (NQ >= 2 && LAYOUT == 1);
+    constexpr bool ASM_PATH = (NQ >= 2);
     constexpr bool INLINE_DMA = (NW == 8);   // refill issued between the MFMA chunks (mg_compute)
-    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, LAYOUT, QG, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
+    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
         thr[j] = (MODE == MODE_FILTER) ? (a.ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
@@ -399,20 +393,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
 
     // ---- per-lane constants of the LDS image
-    // LAYOUT 0, DMA side: lane i of piece (j, half) fetches row 8*half + (i>>3), chunk 8j + ((i&7) ^ ((i>>3)>>1))
-    const int rho = lane >> 3;
-    const int xch = (lane & 7) ^ (rho >> 1);
-    // LAYOUT 0, MFMA side: lane (r,g), k-step (j,e): slot (r&7)*8 + (kappa(g,e) ^ ((r&7)>>1)) of piece (j, r>>3)
-    // LAYOUT 1, MFMA side: lane (r,g), k-step s: byte r*ROWBYTES + 256*(s>>2) + 16*((4*(s&3)+g) ^ r)
+    // MFMA side: lane (r,g), k-step s reads byte r*ROWB + 256*(s>>2) + 16*((4*(s&3)+g) ^ r) of the stage
     int rd_off[4];
-    if (LAYOUT == 0) {
-        rd_off[0] = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 0) ^ ((r & 7) >> 1))) * 16;
-        rd_off[1] = (r >> 3) * 1024 + (((r & 7) * 8) + (kappa(g, 1) ^ ((r & 7) >> 1))) * 16;
-        rd_off[2] = rd_off[3] = 0;
-    } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) rd_off[m] = r * ROWB + 16 * ((4 * m + g) ^ r);
-    }
+    for (int m = 0; m < 4; ++m) rd_off[m] = r * ROWB + 16 * ((4 * m + g) ^ r);
 
     const long long n_work = a.n_work;
     const long long stride = a.tile_stride;
@@ -422,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const long long last_work = n_work - 1;
 
     // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
-    // (LAYOUT 1): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
+    // (DMA side): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
     uint32_t lane_off[PPW];
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
@@ -436,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
         const long long row0 = wk * stride * TILE_ROWS;
         char* slot_base = smem + slot * STAGE_BYTES;
-        if (LAYOUT == 1 && row0 + TILE_ROWS <= n_rows) {
+        if (row0 + TILE_ROWS <= n_rows) {
             // whole tile in range (all but the last tile): uniform base + per-lane constant
             const char* tile = (const char*)rows + row0 * ROWB;
             const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
@@ -447,20 +431,12 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
             const int p = w * PPW + pp;
-            const T* src;
-            if (LAYOUT == 0) {
-                const int j = p >> 1, half = p & 1;
-                long long row = row0 + 8 * half + rho;
-                if (row > last_row) row = last_row;
-                src = rows + row * DIM + (j * 8 + xch) * EPC;
-            } else {
-                const int pos = p * 64 + lane;         // 16-byte slot of the stage this lane fills
-                const int trow = pos / CPR;            // row of the tile the slot belongs to
-                const int chunk = (pos - trow * CPR) ^ (trow & 15);
-                long long row = row0 + trow;
-                if (row > last_row) row = last_row;    // short last tile: re-read the last row
-                src = rows + row * DIM + chunk * EPC;
-            }
+            const int pos = p * 64 + lane;         // 16-byte slot of the stage this lane fills
+            const int trow = pos / CPR;            // row of the tile the slot belongs to
+            const int chunk = (pos - trow * CPR) ^ (trow & 15);
+            long long row = row0 + trow;
+            if (row > last_row) row = last_row;    // short last tile: re-read the last row
+            const T* src = rows + row * DIM + chunk * EPC;
             glds16<AUX>(src, slot_base + p * 1024);
         }
     };
@@ -518,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             if (wave_active) {
                 const char* sb = smem + slot * STAGE_BYTES;
                 f32x4 acc[NQ];
-                if constexpr (NQ == 1 || LAYOUT == 0) {
+                if constexpr (NQ == 1) {
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     // the row fragments of a chunk are all requested before its first MFMA, so the LDS
@@ -531,8 +507,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
                         for (int i = 0; i < CHB; ++i) {
                             const int s = c0 + i;
-                            if (LAYOUT == 0) af[i] = *(const V*)(sb + (s >> 1) * 2048 + rd_off[s & 1]);
-                            else af[i] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
+                            af[i] = *(const V*)(sb + (s >> 2) * 256 + rd_off[s & 3]);
                         }
 #pragma unroll
                         for (int i = 0; i < CHB; ++i) {

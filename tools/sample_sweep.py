@@ -20,13 +20,12 @@ shapes = [tuple(int(x) for x in s.split("x")) for s in sys.argv[1].split(",")]
 divs = [int(x) for x in sys.argv[2].split(",")]
 for nq, k in shapes:
     q = torch.randn((nq, 768), generator=g, device="cuda").half()
-    variants = os.environ.get("VARIANTS", "0").split(",")
+    variants = ["0"]
     for d in divs:
         os.environ["ARTMIPS_SAMPLE_DIV"] = str(d)
         res = {v: ([], []) for v in variants}
         for r in range(6):
             for v in variants:  # interleaved: same process, same device, same data
-                os.environ["ARTMIPS_SCAN_VARIANT"] = v
                 eng.search(q, k)
                 info = eng.info()
                 if r:

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""A/B the experimental builds of the scan kernel in ONE process on ONE index
-(ARTMIPS_SCAN_VARIANT, see launch_scan in art_amd/csrc/artmips.hip): interleaved rounds,
-median and min of the HIP-event time of the FILTER scan per variant."""
+"""A/B settings of the scan in ONE process on ONE index, interleaved rounds, median and min of the
+HIP-event time of the FILTER scan per variant.  Variants are values of an environment knob of the
+library: --nq-sweep (ARTMIPS_MAX_NQ), --shape-sweep (ARTMIPS_NW:ARTMIPS_MAX_NQ[:ARTMIPS_ABLATE]) or
+--env NAME.  (The kernel builds compared in profiles/r01_b_scan_sweep.txt -- LDS image, cache policy,
+ring depth -- were removed from the library once the shipped configuration was chosen.)"""
 import argparse
 import math
 import os
@@ -16,7 +18,7 @@ from art_amd.engine import MipsEngine  # noqa: E402
 
 p = argparse.ArgumentParser()
 p.add_argument("--rows", type=int, default=bench.N_WIKI)
-p.add_argument("--variants", default="0,1,2,3")
+p.add_argument("--variants", required=True)
 p.add_argument("--rounds", type=int, default=6)
 p.add_argument("--queries", type=int, default=64)
 p.add_argument("--topk", type=int, default=32)
@@ -36,17 +38,11 @@ totals = {v: [] for v in variants}
 ref = None
 for rnd in range(args.rounds + 1):
     for v in variants:
-        if not args.shape_sweep and not args.env:
-            os.environ["ARTMIPS_SCAN_VARIANT"] = v.split("x")[0]
-            os.environ["ARTMIPS_GRID_MULT"] = v.split("x")[1] if "x" in v else "1"
         if args.nq_sweep:
-            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ["ARTMIPS_MAX_NQ"] = v
         if args.env:
-            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ[args.env] = v
         if args.shape_sweep:
-            os.environ["ARTMIPS_SCAN_VARIANT"] = "0"
             os.environ["ARTMIPS_NW"], os.environ["ARTMIPS_MAX_NQ"] = v.split(":")[:2]
             os.environ["ARTMIPS_ABLATE"] = v.split(":")[2] if v.count(":") > 1 else "0"
         s, i = eng.search(q, args.topk, score_dtype=torch.float32)
