@@ -97,3 +97,19 @@ def test_eval_shape_k100_q16(big):
     assert bool((i.long()[:, :32] == ref_i[:16, :32]).float().mean() > 0.95)
     for j in range(9):
         assert int(i[j, 0]) == planted[j] + 1
+
+
+def test_large_batch_shape_equals_training_shape(big):
+    # 320 queries in one call (8 waves x 2 groups of 128 per sweep + a 64-query remainder) must give,
+    # query by query, what the 64-query training shape gives: same MFMA k order, so bit-equal scores
+    eng, eng4, queries, planted, ref_s, ref_i = big
+    s64, i64 = eng.search(queries, 32, score_dtype=torch.float32)
+    perm = torch.randperm(320, generator=torch.Generator().manual_seed(7)).to(queries.device)
+    q320 = queries.repeat(5, 1)[perm]
+    s, i = eng.search(q320, 32, score_dtype=torch.float32)
+    assert eng.info()["last_retries"] == 0 and eng.info()["last_scan_launches"] == 2
+    src = perm % 64
+    assert torch.equal(i, i64[src]) and torch.equal(s, s64[src])
+    # and through four shards + merge
+    s4, i4 = eng4.search(q320, 32, score_dtype=torch.float32)
+    assert torch.equal(i4, i) and torch.equal(s4, s)
