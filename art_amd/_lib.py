@@ -14,6 +14,7 @@ F16, BF16, F32 = 0, 1, 2
 MAX_DEVICES = 16
 MAX_K = 2048
 SORT_MAX = 8192
+PACK_TAIL = 4  # ARTMIPS_PACK_TAIL
 
 # every symbol include/artmips.h declares; tests check that the library exports each of them
 SYMBOLS = (
@@ -31,6 +32,7 @@ SYMBOLS = (
     "artmips_search_local_async",
     "artmips_merge_packed",
     "artmips_grow_lists",
+    "artmips_set_stats",
     "artmips_info",
     "artmips_last_error",
     "artmips_version",
@@ -102,6 +104,8 @@ def _load():
     lib.artmips_merge_packed.restype = i32
     lib.artmips_grow_lists.argtypes = [vp]
     lib.artmips_grow_lists.restype = i32
+    lib.artmips_set_stats.argtypes = [vp, i32]
+    lib.artmips_set_stats.restype = i32
     lib.artmips_info.argtypes = [vp, ctypes.POINTER(ArtmipsInfo)]
     lib.artmips_info.restype = i32
     lib.artmips_last_error.argtypes = []

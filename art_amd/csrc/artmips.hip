@@ -100,6 +100,7 @@ struct artmips {
     int last_scan_launches = 0, last_retries = 0;
     int64_t last_candidates = 0;
     int cap_boost = 1;  // sticky multiplier learnt from overflow retries
+    bool stats_enabled = true;         // artmips_set_stats: record HIP events around the kernels
     bool stats_pending = false;
     bool stats_async = false;          // the pending stats belong to artmips_search_local_async
     hipStream_t stats_stream = nullptr;
@@ -603,28 +604,37 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
 
 template <typename T>
 static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int dim, void* out,
-                        int* status_to_clear, hipStream_t st) {
+                        hipStream_t st) {
     hipLaunchKernelGGL(pack_queries_kernel<T>, dim3(q_tile), dim3(256), 0, st, q, q_dtype,
-                       q_count, q_tile, dim, (T*)out, status_to_clear);
+                       q_count, q_tile, dim, (T*)out);
 }
 
 // Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
 static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile, int q_dtype,
                         int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
-                        long long out_row0, hipStream_t st, int tile_index) {
+                        long long out_row0, hipStream_t st, int tile_index, bool timed) {
     const Generation& gen = s.live;
     const int qt = p.nq * p.nw * 16;
-    int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;
-    if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
-    else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
-    else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, clear, st);
-    HIP_TRY(hipGetLastError());
+    int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;  // cleared by kth / fill_thr below
+    // queries already in the storage dtype are read where they lie (columns past q_count re-read the
+    // last row and are never selected); anything else is converted into the padded tile first
+    const void* q_src = q_tile;
+    int q_rows = q_count;
+    if (q_dtype != h->dtype || ((uintptr_t)q_tile & 15) != 0) {
+        if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+        else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+        else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+        HIP_TRY(hipGetLastError());
+        q_src = s.qpad.p;
+        q_rows = qt;
+    }
 
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = gen.rows;
     a.n_rows = gen.n_rows;
-    a.qpad = s.qpad.p;
+    a.qpad = q_src;
+    a.q_rows = q_rows;
     a.q_count = q_count;
     a.thr = (const float*)s.thr.p;
     a.lists = (int2*)s.lists.p;
@@ -641,25 +651,27 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
         const int kth_threads = (p.grid0 * 4 <= 4096) ? 256 : SEL_THREADS;
         hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
-                           (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p);
+                           (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p, clear);
         HIP_TRY(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, (float*)s.thr.p, q_count, qt);
+        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, (float*)s.thr.p, q_count, qt, clear);
         HIP_TRY(hipGetLastError());
     }
 
     a.n_work = p.n_tiles;
     a.tile_stride = 1;
     if (const char* e = getenv("ARTMIPS_ABLATE")) a.ablate = atoi(e);  // diagnostics: wrong results
-    while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
-        s.ev_scan.push_back(e);
+    if (timed) {
+        while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s.ev_scan.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
     }
-    HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
     int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid, st);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
+    if (timed) HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
 
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -699,6 +711,7 @@ struct ShardCall {
     int32_t* out_ids;
     hipStream_t st;
     bool record_stats;
+    bool host_status = true;  // copy the status words to pinned host memory behind the pipeline
     int n_tiles_q = 0;
     std::chrono::steady_clock::time_point t_begin, t_enq;
 };
@@ -746,16 +759,17 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     if (keys_per_q > (size_t)SORT_MAX) {
         if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
     }
-    if (c.record_stats) HIP_TRY(hipEventRecord(s.ev_t0, c.st));
+    const bool timed = c.record_stats && h->stats_enabled;
+    if (timed) HIP_TRY(hipEventRecord(s.ev_t0, c.st));
     c.n_tiles_q = 0;
     for (int64_t q0 = 0; q0 < c.n_q; q0 += QT, ++c.n_tiles_q) {
         const int qc = (int)std::min<int64_t>(QT, c.n_q - q0);
         rc = enqueue_tile(h, s, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
-                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q);
+                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q, timed);
         if (rc) return rc;
     }
-    if (c.record_stats) HIP_TRY(hipEventRecord(s.ev_t1, c.st));
-    HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, c.st));
+    if (timed) HIP_TRY(hipEventRecord(s.ev_t1, c.st));
+    if (c.host_status) HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, c.st));
     c.t_enq = std::chrono::steady_clock::now();
     return 0;
 }
@@ -777,7 +791,7 @@ static int shard_complete(artmips* h, ShardCall& c, bool* overflow) {
         h->host_sync_us = std::chrono::duration<double, std::micro>(t_syn - c.t_enq).count();
         h->stats_slot = c.slot;
         h->stats_tiles = c.n_tiles_q;
-        h->stats_pending = true;  // event times are read when artmips_info asks for them
+        h->stats_pending = h->stats_enabled;  // event times are read when artmips_info asks for them
         h->stats_async = false;
         unsigned long long n = 0;
         memcpy(&n, s.status_host + 2, 8);
@@ -911,6 +925,7 @@ extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_
     if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
     ShardCall c{slot, q_dev, q_dtype, n_q, k, out_packed, ARTMIPS_F32, out_packed + n_q * (int64_t)k,
                 (hipStream_t)stream, true};
+    c.host_status = h->stats_enabled;  // only the candidate count of artmips_info needs it here
     if ((rc = shard_enqueue(h, c))) return rc;
     Shard& s = h->sh[slot];
     DeviceGuard g(s.dev);
@@ -921,10 +936,16 @@ extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_
     h->host_sync_us = 0.0;
     h->stats_slot = slot;
     h->stats_tiles = c.n_tiles_q;
-    h->stats_pending = true;
-    h->stats_async = true;
+    h->stats_pending = h->stats_enabled;
+    h->stats_async = h->stats_enabled;
     h->stats_stream = c.st;
     h->last_retries = 0;
+    return 0;
+}
+
+extern "C" int artmips_set_stats(artmips_t* h, int enabled) {
+    if (!h) return fail(ARTMIPS_ERR_ARG, "NULL handle");
+    h->stats_enabled = enabled != 0;
     return 0;
 }
 

@@ -126,12 +126,12 @@ __device__ __forceinline__ void store_score(void* out, int dtype, int64_t idx, f
 
 // ---------------------------------------------------------------------------------------------
 // pack_queries_kernel: [q_count, dim] (f16 / bf16 / f32) -> [q_tile, dim] storage dtype, zero padded.
+// Only launched when the queries are not in the storage dtype already: otherwise the scan reads the
+// caller's buffer directly (ScanArgs::q_rows).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_queries_kernel(const void* __restrict__ q, int q_dtype, int q_count, int q_tile,
-                                    int dim, T* __restrict__ out, int* __restrict__ status_to_clear) {
-    // first tile of a search: also clear the 16 status words the later kernels raise
-    if (status_to_clear != nullptr && blockIdx.x == 0 && threadIdx.x < 16) status_to_clear[threadIdx.x] = 0;
+                                    int dim, T* __restrict__ out) {
     const int total = q_tile * dim;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int row = i / dim;
@@ -153,7 +153,8 @@ struct ScanArgs {
     long long n_rows;
     long long n_work;     // tiles (or sample tiles) to visit in this launch
     long long tile_stride;// actual tile = work index * tile_stride  (1 for the full scan)
-    const void* qpad;     // [64*NQ, DIM] storage dtype
+    const void* qpad;     // [q_rows, DIM] storage dtype: the caller's queries, or the packed tile
+    int q_rows;           // rows readable at qpad; query columns beyond it re-read row q_rows-1
     int q_count;          // real queries in the tile (<= 64*NQ)
     const float* thr;     // [64*NQ] FILTER: keep score >= thr[q]
     int2* lists;          // FILTER: [grid*NQ*256][cap] (score bits, local row)
@@ -306,19 +307,20 @@ __device__ __forceinline__ void mg_settle(f32x4* acc) {
 // asm path for f >= VB, straight into an AGPR tuple (global_load can target AGPRs; an ordinary load
 // followed by a copy would be re-materialised by hipcc inside the loop).
 template <typename T, int NQ, int KSTEPS, int VB, bool ASM_PATH, int QG, int F, typename V>
-__device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qrow0, int g) {
+__device__ __forceinline__ void load_queries(V (*bq)[KSTEPS], const T* qbase, int col, int q_rows, int g) {
     if constexpr (F < NQ * KSTEPS) {
         constexpr int j = F / KSTEPS, s = F % KSTEPS;
         const int chunk = 4 * s + g;
         constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
         constexpr int DIMQ = KSTEPS * 4 * EPC;              // row width in elements
-        const T* src = qrow0 + (size_t)j * QG * DIMQ + chunk * EPC;
+        const int qrow = (j * QG + col < q_rows) ? (j * QG + col) : (q_rows - 1);
+        const T* src = qbase + (size_t)qrow * DIMQ + chunk * EPC;
         if constexpr (ASM_PATH && F >= VB) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[j][s]) : "v"(src) : "memory");
         } else {
             bq[j][s] = *(const V*)src;
         }
-        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, F + 1, V>(bq, qrow0, g);
+        load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, F + 1, V>(bq, qbase, col, q_rows, g);
     }
 }
 template <int NQ, int KSTEPS, int VB, bool ASM_PATH, int F, typename V>
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     float thr[NQ];
     constexpr bool ASM_PATH = (NQ >= 2);
     constexpr bool INLINE_DMA = (NW == 8);   // refill issued between the MFMA chunks (mg_compute)
-    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, (const T*)a.qpad + (size_t)(w * 16 + r) * DIM, g);
+    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, (const T*)a.qpad, w * 16 + r, a.q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
         thr[j] = (MODE == MODE_FILTER) ? (a.ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
@@ -701,7 +703,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
                                                           int scan_grid, int nq, int k, int q_count,
-                                                          float* __restrict__ thr) {
+                                                          float* __restrict__ thr,
+                                                          int* __restrict__ status_to_clear) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* vals = (uint32_t*)smem;
     __shared__ int hist[256];
@@ -709,6 +712,8 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int G = scan_grid * 4;
+    // first query tile of a search: clear the 16 status words the FILTER scan and the select raise
+    if (status_to_clear != nullptr && q == 0 && tid < 16) status_to_clear[tid] = 0;
     if (q >= q_count) {
         if (tid == 0) thr[q] = INFINITY;  // padded query: never keep anything
         return;
@@ -724,8 +729,9 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
 }
 
 // thresholds when pass 0 is skipped (small shards): keep everything for real queries
-__global__ void fill_thr_kernel(float* thr, int q_count, int q_tile) {
+__global__ void fill_thr_kernel(float* thr, int q_count, int q_tile, int* status_to_clear) {
     const int q = threadIdx.x;
+    if (status_to_clear != nullptr && q < 16) status_to_clear[q] = 0;
     if (q < q_tile) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
 }
 

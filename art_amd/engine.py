@@ -26,6 +26,25 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _on_device(object):
+    """torch.cuda.device(dev) without its cost when dev is the current device already (the per-step
+    path: the GPU idles while the host gets from one step's result to the next step's first launch)."""
+    __slots__ = ("dev", "ctx")
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.ctx = None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.dev.index:
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 class MipsEngine(object):
     """Exact MIPS top-k over row shards resident on one or more GPUs.
 
@@ -103,7 +122,7 @@ class MipsEngine(object):
         n, d = rows.shape
         if d != self.dim or ids.shape != (n,):
             raise ValueError("shape mismatch")
-        with torch.cuda.device(rows.device):
+        with _on_device(rows.device):
             check(lib.artmips_upload_device(self._h, int(slot), ctypes.c_void_p(rows.data_ptr()),
                                             ctypes.c_void_p(ids.data_ptr()), n, int(row_offset),
                                             _stream_ptr(rows.device)))
@@ -123,7 +142,7 @@ class MipsEngine(object):
         n, d = rows.shape
         if d != self.dim or ids.shape != (n,):
             raise ValueError("shape mismatch")
-        with torch.cuda.device(rows.device):
+        with _on_device(rows.device):
             check(lib.artmips_upload_scatter(self._h, rows.device.index, ctypes.c_void_p(rows.data_ptr()),
                                              _abi_dtype(rows.dtype), ctypes.c_void_p(ids.data_ptr()), n,
                                              int(id_base), _stream_ptr(rows.device)))
@@ -163,7 +182,7 @@ class MipsEngine(object):
         dev = q.device
         scores = torch.empty((q.shape[0], top_k), dtype=score_dtype, device=dev)
         ids = torch.empty((q.shape[0], top_k), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.artmips_search(self._h, ctypes.c_void_p(q.data_ptr()), _abi_dtype(q.dtype),
                                      q.shape[0], top_k, ctypes.c_void_p(scores.data_ptr()),
                                      _abi_dtype(score_dtype), ctypes.c_void_p(ids.data_ptr()),
@@ -180,7 +199,7 @@ class MipsEngine(object):
         dev = q.device
         scores = torch.empty((q.shape[0], top_k), dtype=torch.float32, device=dev)
         ids = torch.empty((q.shape[0], top_k), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.artmips_search_local(self._h, int(slot), ctypes.c_void_p(q.data_ptr()),
                                            _abi_dtype(q.dtype), q.shape[0], top_k,
                                            ctypes.c_void_p(scores.data_ptr()),
@@ -202,7 +221,7 @@ class MipsEngine(object):
         dev = scores.device
         out_s = torch.empty((nq, k), dtype=score_dtype, device=dev)
         out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.artmips_merge(dev.index, ctypes.c_void_p(scores.data_ptr()),
                                     ctypes.c_void_p(ids.data_ptr()), g, nq, k,
                                     ctypes.c_void_p(out_s.data_ptr()), _abi_dtype(score_dtype),
@@ -212,7 +231,7 @@ class MipsEngine(object):
     # ---- SPMD step without a host round trip (include/artmips.h, "the SPMD step ...") ----------
     @staticmethod
     def packed_words(n_q, top_k):
-        return int(lib.artmips_packed_words(int(n_q), int(top_k)))
+        return 2 * int(n_q) * int(top_k) + _lib.PACK_TAIL  # = artmips_packed_words(n_q, top_k)
 
     def search_local_async(self, slot, queries, top_k, out_packed):
         """Enqueue the local top-k of shard `slot` into out_packed (int32 [packed_words(Q, k)]:
@@ -225,13 +244,13 @@ class MipsEngine(object):
                 or out_packed.device != q.device
                 or out_packed.numel() != self.packed_words(q.shape[0], top_k)):
             raise ValueError("out_packed must be a contiguous CUDA int32 tensor of packed_words(Q, k) words")
-        with torch.cuda.device(q.device):
+        with _on_device(q.device):
             check(lib.artmips_search_local_async(self._h, int(slot), ctypes.c_void_p(q.data_ptr()),
                                                  _abi_dtype(q.dtype), q.shape[0], top_k,
                                                  ctypes.c_void_p(out_packed.data_ptr()),
                                                  _stream_ptr(q.device)))
-        # the library reads q after this returns: keep it alive until the stream gets there
-        q.record_stream(torch.cuda.current_stream(q.device))
+        if q is not queries:  # a contiguous copy the library reads after this returns: keep it alive
+            q.record_stream(torch.cuda.current_stream(q.device))
 
     @staticmethod
     def merge_packed(packed, n_q, top_k, score_dtype=torch.float16, out_flag=None):
@@ -246,7 +265,7 @@ class MipsEngine(object):
         out_s = torch.empty((n_q, top_k), dtype=score_dtype, device=dev)
         out_i = torch.empty((n_q, top_k), dtype=torch.int32, device=dev)
         flag_ptr = ctypes.c_void_p(out_flag.data_ptr()) if out_flag is not None else ctypes.c_void_p()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.artmips_merge_packed(dev.index, ctypes.c_void_p(packed.data_ptr()), packed.shape[0],
                                            int(n_q), int(top_k), ctypes.c_void_p(out_s.data_ptr()),
                                            _abi_dtype(score_dtype), ctypes.c_void_p(out_i.data_ptr()),
@@ -255,6 +274,10 @@ class MipsEngine(object):
 
     def grow_lists(self):
         check(lib.artmips_grow_lists(self._h))
+
+    def set_stats(self, enabled):
+        """HIP-event timing of the pipeline on/off (info() keeps the last timed call when off)."""
+        check(lib.artmips_set_stats(self._h, 1 if enabled else 0))
 
     def info(self):
         out = _lib.ArtmipsInfo()

@@ -369,3 +369,28 @@ def test_bf16_large_batch_shapes(gu, n, q, k):
     assert n_diff <= max(2, (q * k) // 500)
     assert eng.info()["last_retries"] == 0
     eng.close()
+
+
+def test_queries_read_in_place_sliced_and_unaligned(gu):
+    """Queries in the storage dtype are read where they lie (no packing kernel): a row slice of a
+    larger tensor, a ragged count, and a view whose base is not 16-byte aligned (which must take the
+    packing path instead) all give the result of a fresh contiguous copy."""
+    rows, queries, ids = _random_case(30000, 70, 768, seed=31)
+    eng = gu.build_engine(rows, ids)
+    big = torch.from_numpy(queries).cuda()
+    want_s, want_i = eng.search(big.clone(), 20, score_dtype=torch.float32)
+    s, i = eng.search(big[3:10], 20, score_dtype=torch.float32)           # slice: offset base, 7 queries
+    assert torch.equal(i, want_i[3:10]) and torch.equal(s, want_s[3:10])
+    flat = torch.empty(70 * 768 + 8, dtype=torch.float16, device="cuda")
+    unaligned = flat[1:1 + 70 * 768].view(70, 768)                         # base = 2 bytes past alignment
+    unaligned.copy_(big)
+    assert unaligned.data_ptr() % 16 != 0 and unaligned.is_contiguous()
+    s, i = eng.search(unaligned, 20, score_dtype=torch.float32)
+    assert torch.equal(i, want_i) and torch.equal(s, want_s)
+    # timing off: the search still works and info() keeps the last timed call
+    timed = eng.info()["last_scan_ms"]
+    eng.set_stats(False)
+    s, i = eng.search(big, 20, score_dtype=torch.float32)
+    assert torch.equal(i, want_i) and eng.info()["last_scan_ms"] == timed
+    eng.set_stats(True)
+    eng.close()
