@@ -28,6 +28,7 @@ N_WIKI = 21015324  # 32 GB fp16 evidence file of the reference README (SURVEY.md
 DIM = 768
 HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
 STAT_EVERY = 4  # steps between two HIP-event timings of the scan kernel
+PREWARM_STEPS = 16  # untimed steps after the idle settle window (clock ramp), before the W warm-up steps
 
 
 def parse():
@@ -149,6 +150,11 @@ def main():
     if left > 0:
         time.sleep(left)
 
+    # The idle window leaves the GPU in its low-power state and the first ~10 launches after it run up
+    # to 25 % slower while the clocks ramp (profiles/r01_q_README.txt): PREWARM_STEPS untimed steps
+    # bring it back to the state a training loop keeps it in, then the W warm-up steps follow.
+    for _ in range(PREWARM_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -201,6 +207,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": PREWARM_STEPS,
+            "settle_seconds": args.settle_seconds,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
