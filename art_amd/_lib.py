@@ -31,6 +31,8 @@ SYMBOLS = (
     "artmips_packed_words",
     "artmips_search_local_async",
     "artmips_merge_packed",
+    "artmips_merge_packed_sync",
+    "artmips_fetch_rows",
     "artmips_grow_lists",
     "artmips_set_stats",
     "artmips_info",
@@ -102,6 +104,10 @@ def _load():
     lib.artmips_search_local_async.restype = i32
     lib.artmips_merge_packed.argtypes = [i32, vp, i32, i64, i32, vp, i32, vp, vp, vp]
     lib.artmips_merge_packed.restype = i32
+    lib.artmips_merge_packed_sync.argtypes = [i32, vp, i32, i64, i32, vp, i32, vp, ctypes.POINTER(ctypes.c_int32), vp]
+    lib.artmips_merge_packed_sync.restype = i32
+    lib.artmips_fetch_rows.argtypes = [vp, vp, i64, vp]
+    lib.artmips_fetch_rows.restype = i32
     lib.artmips_grow_lists.argtypes = [vp]
     lib.artmips_grow_lists.restype = i32
     lib.artmips_set_stats.argtypes = [vp, i32]

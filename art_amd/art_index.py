@@ -14,7 +14,9 @@ Differences from the reference, all deliberate:
     scores with torch.topk's unspecified tie order, art_index.py:280-294);
   * one process still drives every visible GPU (art_index.py:204), but only
     Q*k (score, id) pairs per GPU move between devices instead of [Q, N/G] slabs;
-  * ``FaissMIPSIndex`` is not provided (faiss is out of scope).
+  * ``FaissMIPSIndex`` keeps the reference's constructor, methods and numpy return types
+    (art_index.py:103-197) but is served by the same HIP library: faiss itself is out of
+    scope and is never imported.
 """
 import os
 import pickle
@@ -286,7 +288,97 @@ class DistributedBruteForceIndex(object):
         ignored exactly as in the reference (art_index.py:267-270)."""
         if self.evidence_embeds is None:
             raise RuntimeError("MIPS index is empty: call add_embed_data first")
+        if query_embeds.dim() == 2 and query_embeds.shape[0] == 0:
+            # no queries: the reference's matmul + topk give empty [0, k] results
+            return (torch.empty((0, int(top_k)), dtype=self.score_dtype, device=query_embeds.device),
+                    torch.empty((0, int(top_k)), dtype=torch.int32, device=query_embeds.device))
         return self.evidence_embeds.search(query_embeds, top_k, score_dtype=self.score_dtype)
 
 
-__all__ = ["detach", "OpenRetreivalDataStore", "DistributedBruteForceIndex"]
+class FaissMIPSIndex(object):
+    """The reference's faiss-backed sibling (art_index.py:103-197) with the same constructor,
+    methods and return types, served by libartmips instead of faiss.
+
+    ``search_mips_index`` takes a torch tensor on any device and returns **numpy** arrays like
+    ``faiss.IndexIDMap.search``: ``(distances float32 [Q, k], ids int64 [Q, k])``; with
+    ``reconstruct=True`` (the reference's default, art_index.py:190-193:
+    ``search_and_reconstruct``) the stored vectors come back as a third array float32 [Q, k, dim].
+    The callers already accept this form (evaluate.py:155-157).
+
+    ``use_gpu=False`` is the reference's exact fp32 ``IndexFlatIP``: rows are kept in fp32 (the
+    store's fp16 values widened, as art_index.py:171 does) and fp32 queries are not rounded.
+    ``use_gpu=True`` is its ``useFloat16`` GPU index (art_index.py:125-131): fp16 rows, queries
+    rounded to fp16, fp32 accumulation.  Both run on the GPUs; there is no CPU search path.
+    Differences: exact ties are broken by the lower passage id (faiss: unspecified), and slots beyond
+    the number of rows cannot occur because top_k <= rows is enforced (faiss pads with id -1)."""
+
+    def __init__(self, embed_size, embed_data=None, use_gpu=False, devices=None):
+        self.embed_size = embed_size
+        self.embed_data = embed_data
+        self.use_gpu = use_gpu
+        self.devices = devices
+
+        self.mips_index = None
+        self._row_of_id = None
+        self._set_mips_index()
+
+    def _set_mips_index(self):
+        if _is_main_printer():
+            print("\n> Building FAISS-shaped index on libartmips", flush=True)
+        storage = torch.float16 if self.use_gpu else torch.float32
+        self.mips_index = DistributedBruteForceIndex(self.embed_size, None, devices=self.devices,
+                                                     storage_dtype=storage)
+        self.mips_index.score_dtype = torch.float32
+        if self.embed_data is not None:
+            self.add_embed_data(self.embed_data)
+
+    def _drop(self):
+        if self.mips_index is not None:
+            self.mips_index._free()
+        self.mips_index = None
+
+    def reset_index(self):
+        self._drop()
+        if self.embed_data is not None:
+            embed_data_path = self.embed_data.embedding_path
+            del self.embed_data
+            self.embed_data = OpenRetreivalDataStore(embed_data_path)
+        self._set_mips_index()
+
+    def update_index(self):
+        self._drop()
+        if self.embed_data is not None:
+            self.embed_data.load_from_file()
+        self._set_mips_index()
+
+    def add_embed_data(self, all_embed_data):
+        """Add every embedding of the store to the index and clear the store (art_index.py:164-180)."""
+        self.mips_index.add_embed_data(all_embed_data)
+        self._row_of_id = None
+
+    def _rows_of_ids(self, ids):
+        # passage id -> row position, built on first use (reconstruct only)
+        if self._row_of_id is None:
+            arr = self.mips_index.indices_arr
+            order = np.argsort(arr, kind="stable")
+            self._row_of_id = (arr[order], order)
+        sorted_ids, order = self._row_of_id
+        return order[np.searchsorted(sorted_ids, ids)]
+
+    def search_mips_index(self, query_embeds, top_k, reconstruct=True):
+        index = self.mips_index
+        if index is None or index.evidence_embeds is None:
+            raise RuntimeError("MIPS index is empty: call add_embed_data first")
+        dev = torch.device("cuda", index.devices[0])
+        # faiss takes float32 queries (art_index.py:188); the library rounds them to the storage dtype
+        q = query_embeds.detach().to(device=dev, dtype=torch.float32)
+        distances, ids = index.search_mips_index(q, top_k, reconstruct=False)
+        distances = distances.cpu().numpy()
+        ids = ids.cpu().numpy().astype(np.int64)
+        if not reconstruct:
+            return distances, ids
+        rows = index.evidence_embeds.fetch_rows(self._rows_of_ids(ids.reshape(-1)))
+        return distances, ids, rows.reshape(ids.shape[0], ids.shape[1], self.embed_size)
+
+
+__all__ = ["detach", "OpenRetreivalDataStore", "DistributedBruteForceIndex", "FaissMIPSIndex"]

@@ -612,10 +612,10 @@ static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int
 // Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
 static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile, int q_dtype,
                         int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
-                        long long out_row0, hipStream_t st, int tile_index, bool timed) {
+                        long long out_row0, hipStream_t st, int tile_index, bool timed, int* status) {
     const Generation& gen = s.live;
     const int qt = p.nq * p.nw * 16;
-    int* clear = (tile_index == 0) ? (int*)s.status.p : nullptr;  // cleared by kth / fill_thr below
+    int* clear = (tile_index == 0) ? status : nullptr;  // cleared by kth / fill_thr below
     // queries already in the storage dtype are read where they lie (columns past q_count re-read the
     // last row and are never selected); anything else is converted into the padded tile first
     const void* q_src = q_tile;
@@ -689,8 +689,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     sa.score_dtype = score_dtype;
     sa.out_ids = out_ids;
     sa.out_row0 = out_row0;
-    sa.status = (int*)s.status.p;
-    sa.cand_total = (unsigned long long*)((int*)s.status.p + 2);
+    sa.status = status;
+    sa.cand_total = (unsigned long long*)(status + 2);
     // few candidates per query (small k): 4 waves sort faster than 16 (cheaper barriers)
     const int sel_threads = (k <= 128 && p.pass0) ? 256 : SEL_THREADS;
     hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(sel_threads), 0, st, sa);
@@ -712,6 +712,8 @@ struct ShardCall {
     hipStream_t st;
     bool record_stats;
     bool host_status = true;  // copy the status words to pinned host memory behind the pipeline
+    int* status_dev = nullptr;  // 16 status words on the shard's device, 8-byte aligned; NULL = the
+                                // shard's own block (the async path raises them in the packed tail)
     int n_tiles_q = 0;
     std::chrono::steady_clock::time_point t_begin, t_enq;
 };
@@ -761,15 +763,16 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     }
     const bool timed = c.record_stats && h->stats_enabled;
     if (timed) HIP_TRY(hipEventRecord(s.ev_t0, c.st));
+    int* const status = c.status_dev ? c.status_dev : (int*)s.status.p;
     c.n_tiles_q = 0;
     for (int64_t q0 = 0; q0 < c.n_q; q0 += QT, ++c.n_tiles_q) {
         const int qc = (int)std::min<int64_t>(QT, c.n_q - q0);
         rc = enqueue_tile(h, s, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
-                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q, timed);
+                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q, timed, status);
         if (rc) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(s.ev_t1, c.st));
-    if (c.host_status) HIP_TRY(hipMemcpyAsync(s.status_host, s.status.p, 16, hipMemcpyDeviceToHost, c.st));
+    if (c.host_status) HIP_TRY(hipMemcpyAsync(s.status_host, status, 16, hipMemcpyDeviceToHost, c.st));
     c.t_enq = std::chrono::steady_clock::now();
     return 0;
 }
@@ -849,6 +852,8 @@ extern "C" int artmips_search_local(artmips_t* h, int slot, const void* q_dev, i
 // still in flight on some stream never loses its scratch.
 struct MergeScratch {
     DevBuf keys, status;
+    int32_t* flag_host = nullptr;  // pinned word the merge kernel writes over the bus (merge_packed_sync)
+    int32_t* flag_dev = nullptr;   // its address as the device sees it
 };
 static MergeScratch g_merge_scratch[ARTMIPS_MAX_DEVICES * 4];
 static std::mutex g_merge_mutex;
@@ -909,6 +914,8 @@ extern "C" int artmips_merge(int device, const float* scores, const int32_t* ids
                      (hipStream_t)stream, &ms.keys, &ms.status);
 }
 
+static_assert(ARTMIPS_PACK_TAIL == 4, "the kernels clear and raise exactly 4 status words");
+
 extern "C" int64_t artmips_packed_words(int64_t n_q, int k) {
     return 2 * n_q * (int64_t)k + ARTMIPS_PACK_TAIL;
 }
@@ -926,12 +933,17 @@ extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_
     ShardCall c{slot, q_dev, q_dtype, n_q, k, out_packed, ARTMIPS_F32, out_packed + n_q * (int64_t)k,
                 (hipStream_t)stream, true};
     c.host_status = h->stats_enabled;  // only the candidate count of artmips_info needs it here
+    // The shard's status words travel with the candidates, so that whoever merges them sees the
+    // overflow bit: the kernels raise them in the tail of out_packed itself (an 8-byte aligned tail;
+    // otherwise they are copied there behind the pipeline).
+    int32_t* const tail = out_packed + 2 * n_q * (int64_t)k;
+    const bool in_place = (((uintptr_t)tail) & 7) == 0;
+    if (in_place) c.status_dev = (int*)tail;
     if ((rc = shard_enqueue(h, c))) return rc;
     Shard& s = h->sh[slot];
     DeviceGuard g(s.dev);
-    // the shard's status words travel with the candidates: whoever merges them sees the overflow bit
-    HIP_TRY(hipMemcpyAsync(out_packed + 2 * n_q * (int64_t)k, s.status.p, ARTMIPS_PACK_TAIL * 4,
-                           hipMemcpyDeviceToDevice, c.st));
+    if (!in_place)
+        HIP_TRY(hipMemcpyAsync(tail, s.status.p, ARTMIPS_PACK_TAIL * 4, hipMemcpyDeviceToDevice, c.st));
     h->host_enqueue_us = std::chrono::duration<double, std::micro>(c.t_enq - c.t_begin).count();
     h->host_sync_us = 0.0;
     h->stats_slot = slot;
@@ -971,6 +983,33 @@ extern "C" int artmips_merge_packed(int device, const int32_t* packed, int n_lis
     return run_merge(device, (const float*)packed, packed + plane, n_lists, n_q, k, out_scores, score_dtype,
                      out_ids, (hipStream_t)stream, &ms.keys, &ms.status, stride,
                      out_flag ? packed + 2 * plane : nullptr, stride, out_flag);
+}
+
+extern "C" int artmips_merge_packed_sync(int device, const int32_t* packed, int n_lists, int64_t n_q, int k,
+                                         void* out_scores, int score_dtype, int32_t* out_ids,
+                                         int32_t* flag_host_out, void* stream) {
+    if (!packed || !out_scores || !out_ids || !flag_host_out) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (n_lists < 1 || n_q < 1 || k < 1) return fail(ARTMIPS_ERR_ARG, "n_lists, n_q and k must be >= 1");
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
+    if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
+    const long long plane = (long long)n_q * k;
+    const long long stride = 2 * plane + ARTMIPS_PACK_TAIL;
+    // the lock is held across the wait: the pinned flag word is one per device
+    std::lock_guard<std::mutex> lock(g_merge_mutex);
+    MergeScratch& ms = g_merge_scratch[device];
+    DeviceGuard g(device);
+    if (!ms.flag_host) {
+        HIP_TRY(hipHostMalloc((void**)&ms.flag_host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&ms.flag_dev, ms.flag_host, 0));
+    }
+    int rc = run_merge(device, (const float*)packed, packed + plane, n_lists, n_q, k, out_scores, score_dtype,
+                       out_ids, (hipStream_t)stream, &ms.keys, &ms.status, stride, packed + 2 * plane, stride,
+                       ms.flag_dev);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // kernel end makes the word visible to the host
+    *flag_host_out = *(volatile int32_t*)ms.flag_host;
+    return 0;
 }
 
 extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
@@ -1056,6 +1095,60 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
     if (rc) return rc;
     DeviceGuard g(s0.dev);
     HIP_TRY(hipStreamSynchronize(st));  // the search entry points return with the stream drained
+    return 0;
+}
+
+template <typename T>
+static void launch_gather(const Generation& g, int dim, const long long* pos, long long n, float* out,
+                          hipStream_t st) {
+    const int grid = (int)std::min<long long>(n, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)g.rows, dim, pos, n,
+                       (long long)g.n_rows, out);
+}
+
+extern "C" int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_t n, float* out_host) {
+    if (!h || !positions || !out_host) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (h->n_rows < 1) return fail(ARTMIPS_ERR_STATE, "fetch from an empty index (no artmips_finalize yet)");
+    if (n < 0) return fail(ARTMIPS_ERR_ARG, "n must be >= 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (positions[i] < 0 || positions[i] >= h->n_rows)
+            return fail(ARTMIPS_ERR_ARG, "row position %lld outside the %lld rows of the index",
+                        (long long)positions[i], (long long)h->n_rows);
+    // rarely used, so kept simple: per shard, the positions that fall inside it are sent over, the
+    // rows come back as fp32 and are put where they belong in out_host
+    std::vector<long long> local, where;
+    std::vector<float> tmp;
+    for (int sidx = 0; sidx < h->n_dev; ++sidx) {
+        Shard& s = h->sh[sidx];
+        if (s.live.n_rows == 0) continue;
+        local.clear();
+        where.clear();
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t p = positions[i] - s.live.row0;
+            if (p >= 0 && p < s.live.n_rows) { local.push_back(p); where.push_back(i); }
+        }
+        if (local.empty()) continue;
+        DeviceGuard g(s.dev);
+        const size_t m = local.size();
+        void *d_pos = nullptr, *d_out = nullptr;
+        hipError_t e = hipMalloc(&d_pos, m * 8);
+        if (e == hipSuccess) e = hipMalloc(&d_out, m * (size_t)h->dim * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_pos, local.data(), m * 8, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) {
+            if (h->dtype == ARTMIPS_F16) launch_gather<_Float16>(s.live, h->dim, (const long long*)d_pos, (long long)m, (float*)d_out, s.stream);
+            else if (h->dtype == ARTMIPS_BF16) launch_gather<__bf16>(s.live, h->dim, (const long long*)d_pos, (long long)m, (float*)d_out, s.stream);
+            else launch_gather<float>(s.live, h->dim, (const long long*)d_pos, (long long)m, (float*)d_out, s.stream);
+            e = hipGetLastError();
+        }
+        tmp.resize(m * (size_t)h->dim);
+        if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d_out, m * (size_t)h->dim * 4, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_out) (void)hipFree(d_out);
+        if (e != hipSuccess) return fail(ARTMIPS_ERR_HIP, "row fetch on shard %d failed: %s", sidx, hipGetErrorString(e));
+        for (size_t j = 0; j < m; ++j)
+            memcpy(out_host + (size_t)where[j] * h->dim, tmp.data() + j * (size_t)h->dim, (size_t)h->dim * 4);
+    }
     return 0;
 }
 

@@ -712,8 +712,9 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int G = scan_grid * 4;
-    // first query tile of a search: clear the 16 status words the FILTER scan and the select raise
-    if (status_to_clear != nullptr && q == 0 && tid < 16) status_to_clear[tid] = 0;
+    // first query tile of a search: clear the 4 status words (flags, pad, 64-bit candidate count) the
+    // select raises; they may be the status tail of a packed candidate list, which is 4 words long
+    if (status_to_clear != nullptr && q == 0 && tid < 4) status_to_clear[tid] = 0;
     if (q >= q_count) {
         if (tid == 0) thr[q] = INFINITY;  // padded query: never keep anything
         return;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
 // thresholds when pass 0 is skipped (small shards): keep everything for real queries
 __global__ void fill_thr_kernel(float* thr, int q_count, int q_tile, int* status_to_clear) {
     const int q = threadIdx.x;
-    if (status_to_clear != nullptr && q < 16) status_to_clear[q] = 0;
+    if (status_to_clear != nullptr && q < 4) status_to_clear[q] = 0;
     if (q < q_tile) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
 }
 
@@ -1058,6 +1059,19 @@ __global__ void count_unfilled_kernel(const int32_t* __restrict__ row_ids, long 
         mine += (row_ids[i] == ID_SENTINEL) ? 1ull : 0ull;
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
+// Fetch rows by local position as fp32 (the "reconstruct" half of the faiss-shaped sibling API,
+// art_index.py:190-193).  One 256-thread workgroup per fetched row (grid-strided).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ rows, int dim,
+                                                          const long long* __restrict__ pos, long long n,
+                                                          long long n_rows, float* __restrict__ out) {
+    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long p = pos[i];
+        for (int c = threadIdx.x; c < dim; c += blockDim.x)
+            out[i * dim + c] = (p >= 0 && p < n_rows) ? (float)rows[p * dim + c] : 0.0f;
+    }
 }
 
 }  // namespace artk

@@ -51,8 +51,9 @@ def spmd_search(local_search, merge, queries, top_k, group=None):
 class SpmdSearcher(object):
     """The SPMD step of a one-shard MipsEngine with one collective and one host wait:
 
-        search_local_async (no wait) -> all_gather_into_tensor of the packed list -> merge_packed
-        -> read ONE int32 flag (OR of every rank's overflow bit, identical on all ranks).
+        search_local_async (no wait) -> all_gather_into_tensor of the packed list -> merge_packed_sync
+        (merge + ONE stream wait + ONE int32 flag: the OR of every rank's overflow bit, identical on
+        all ranks, written by the merge kernel into a pinned host word).
 
     Everything up to the flag read is only enqueued, so the launch latency of the collective and of
     the merge hides behind the scan.  If some rank's candidate lists overflowed (rare: the lists
@@ -66,6 +67,8 @@ class SpmdSearcher(object):
         self.always_gather = always_gather  # run the collective even with one rank (measurements)
         self._bufs = {}
         self.last_retries = 0
+        self._world = None
+        self._nccl = False
 
     def _buffers(self, n_q, top_k, world, dev):
         key = (n_q, top_k, world)
@@ -77,7 +80,7 @@ class SpmdSearcher(object):
             gathered = torch.empty((world, words), dtype=torch.int32, device=dev)
             alias = (world == 1 and not self.always_gather)
             local = gathered[0] if alias else torch.empty((words,), dtype=torch.int32, device=dev)
-            b = (local, gathered, torch.zeros((1,), dtype=torch.int32, device=dev))
+            b = (local, gathered)
             if len(self._bufs) >= 8:
                 self._bufs.clear()
             self._bufs[key] = b
@@ -86,19 +89,24 @@ class SpmdSearcher(object):
     def search(self, queries, top_k, score_dtype=torch.float16):
         from .engine import MipsEngine
 
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self._world is None:  # the group does not change under a searcher: ask once
+            self._world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+            self._nccl = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        world = self._world
         n_q = queries.shape[0]
-        local, gathered, flag = self._buffers(n_q, int(top_k), world, queries.device)
+        local, gathered = self._buffers(n_q, int(top_k), world, queries.device)
         self.last_retries = 0
         while True:
             self.engine.search_local_async(0, queries, top_k, local)
             if world > 1 or self.always_gather:
-                if dist.get_backend(self.group) == "nccl":
+                if self._nccl:
                     dist.all_gather_into_tensor(gathered, local, group=self.group)
                 else:  # gloo (tests): the rows of `gathered` are contiguous views
                     dist.all_gather(list(gathered.unbind(0)), local, group=self.group)
-            out = MipsEngine.merge_packed(gathered, n_q, top_k, score_dtype, flag)
-            status = int(flag.item())  # the step's only host wait
+            # the step's only host wait: the merge writes the flag into a pinned host word and the
+            # stream is synchronised inside the call (no device-to-host copy behind the merge)
+            s, i, status = MipsEngine.merge_packed_sync(gathered, n_q, top_k, score_dtype)
+            out = (s, i)
             if status & 2:
                 raise RuntimeError("artmips: internal key scratch too small on some rank")
             if not (status & 1):

@@ -272,6 +272,36 @@ class MipsEngine(object):
                                            flag_ptr, _stream_ptr(dev)))
         return out_s, out_i
 
+    @staticmethod
+    def merge_packed_sync(packed, n_q, top_k, score_dtype=torch.float16):
+        """merge_packed plus the step's one host wait: returns (scores, ids, flag) with flag the OR of
+        the lists' status words, read from a pinned host word the merge kernel wrote (no device-to-host
+        copy is queued).  The current stream is synchronised on return."""
+        if packed.dim() != 2 or packed.dtype != torch.int32 or not packed.is_cuda or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous CUDA int32 tensor [G, words]")
+        if packed.shape[1] != MipsEngine.packed_words(n_q, top_k):
+            raise ValueError("packed lists have %d words, expected %d"
+                             % (packed.shape[1], MipsEngine.packed_words(n_q, top_k)))
+        dev = packed.device
+        out_s = torch.empty((n_q, top_k), dtype=score_dtype, device=dev)
+        out_i = torch.empty((n_q, top_k), dtype=torch.int32, device=dev)
+        flag = ctypes.c_int32(0)
+        with _on_device(dev):
+            check(lib.artmips_merge_packed_sync(dev.index, ctypes.c_void_p(packed.data_ptr()), packed.shape[0],
+                                                int(n_q), int(top_k), ctypes.c_void_p(out_s.data_ptr()),
+                                                _abi_dtype(score_dtype), ctypes.c_void_p(out_i.data_ptr()),
+                                                ctypes.byref(flag), _stream_ptr(dev)))
+        return out_s, out_i, flag.value
+
+    def fetch_rows(self, positions):
+        """Rows of the live index at the given global row positions, as a float32 numpy array
+        [n, dim] (faiss's reconstruct, art_index.py:190-193)."""
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64).reshape(-1))
+        out = np.empty((pos.shape[0], self.dim), dtype=np.float32)
+        check(lib.artmips_fetch_rows(self._h, ctypes.c_void_p(pos.ctypes.data), pos.shape[0],
+                                     ctypes.c_void_p(out.ctypes.data)))
+        return out
+
     def grow_lists(self):
         check(lib.artmips_grow_lists(self._h))
 

@@ -165,7 +165,8 @@ int64_t artmips_packed_words(int64_t n_q, int k);
 
 /* artmips_search_local (art_index.py:278-280,294) without the wait and without the
  * overflow retry: enqueues the shard's pipeline on `stream` and returns.  The
- * overflow bit travels in the status tail of out_packed instead. */
+ * overflow bit travels in the status tail of out_packed instead (the kernels raise it
+ * there directly when out_packed is 8-byte aligned). */
 int artmips_search_local_async(artmips_t* h, int slot, const void* q_dev, int q_dtype, int64_t n_q,
                                int k, int32_t* out_packed, void* stream);
 
@@ -177,9 +178,24 @@ int artmips_merge_packed(int device, const int32_t* packed, int n_lists, int64_t
                          void* out_scores, int score_dtype, int32_t* out_ids, int32_t* out_flag,
                          void* stream);
 
+/* artmips_merge_packed followed by the step's one host wait: the merge writes the OR of
+ * the lists' status words straight into a pinned host word (no device-to-host copy is
+ * queued), `stream` is synchronised and the word is returned in *flag_host_out (a HOST
+ * pointer).  On return the merged lists are complete.  Calls on one device are serialised. */
+int artmips_merge_packed_sync(int device, const int32_t* packed, int n_lists, int64_t n_q, int k,
+                              void* out_scores, int score_dtype, int32_t* out_ids,
+                              int32_t* flag_host_out, void* stream);
+
 /* After a flag with bit 0 set: make the candidate lists of this handle 8x larger
  * (what artmips_search does internally before it retries), then repeat the step. */
 int artmips_grow_lists(artmips_t* h);
+
+/* Read n rows of the live index back to the host as fp32: positions[i] is a global row
+ * position (0-based, in upload order; the reference's id_map maps them to passage ids,
+ * art_index.py:257-259), out_host is [n, dim] floats.  Serves the `reconstruct=True`
+ * half of the sibling index's search (FaissMIPSIndex.search_mips_index,
+ * art_index.py:190-193: faiss's search_and_reconstruct).  Synchronous. */
+int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_t n, float* out_host);
 
 /* Turn the HIP-event timing of the search pipeline on (default) or off.  The event records sit
  * between the kernels in the stream and cost a few microseconds each, which is noise on a 32 GB

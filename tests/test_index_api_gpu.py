@@ -79,3 +79,54 @@ def test_index_without_store_and_errors(tmp_path):
     index = DistributedBruteForceIndex(embed_size=768, embed_data=None)
     with pytest.raises(RuntimeError):
         index.search_mips_index(torch.zeros(1, 768, dtype=torch.float16, device="cuda"), 1)
+
+
+def test_empty_query_batch_returns_empty_like_the_reference(tmp_path):
+    """torch.matmul + torch.topk on a [0, 768] query batch give [0, k] results (art_index.py:280,294);
+    the drop-in does the same instead of raising."""
+    from art_amd.art_index import DistributedBruteForceIndex, OpenRetreivalDataStore
+    path, rows, ids = _store(tmp_path, n=300)
+    index = DistributedBruteForceIndex(embed_size=768, embed_data=OpenRetreivalDataStore(path))
+    d, i = index.search_mips_index(torch.zeros(0, 768, dtype=torch.float16, device="cuda"), 7, reconstruct=False)
+    assert tuple(d.shape) == (0, 7) and tuple(i.shape) == (0, 7)
+    assert d.dtype == torch.float16 and i.dtype == torch.int32 and d.is_cuda
+
+
+@pytest.mark.parametrize("use_gpu", [False, True])
+def test_faiss_shaped_index(tmp_path, use_gpu):
+    """FaissMIPSIndex keeps the reference's surface (art_index.py:103-197): constructor, numpy
+    returns (float32 distances, int64 ids), reconstruct=True returning the stored vectors, and
+    update_index / reset_index.  use_gpu=False is the exact-fp32 IndexFlatIP (fp32 queries are
+    not rounded), use_gpu=True the useFloat16 GPU index (queries rounded to fp16)."""
+    from art_amd.art_index import FaissMIPSIndex, OpenRetreivalDataStore
+    path, rows, ids = _store(tmp_path, n=2500, seed=5)
+    store = OpenRetreivalDataStore(path, load_from_path=True)
+    index = FaissMIPSIndex(embed_size=768, embed_data=store, use_gpu=use_gpu)
+    assert store.embed_data == {}  # art_index.py:175
+    rng = np.random.Generator(np.random.PCG64(21))
+    queries = rng.standard_normal((10, 768)).astype(np.float32)
+    q = torch.from_numpy(queries)  # a CPU tensor, as evaluate.py may pass (art_index.py:188 calls .cpu())
+    dist, idx = index.search_mips_index(q, 20, reconstruct=False)
+    assert isinstance(dist, np.ndarray) and isinstance(idx, np.ndarray)
+    assert dist.dtype == np.float32 and idx.dtype == np.int64 and dist.shape == (10, 20) and idx.shape == (10, 20)
+    # evaluate.py:155-157 turns them into the tensors it broadcasts
+    torch.from_numpy(dist).half().cuda(), torch.from_numpy(idx).int().cuda()
+    q_seen = queries.astype(np.float16) if use_gpu else queries
+    orc.check_topk(dist, idx.astype(np.int32), q_seen.astype(np.float64), rows.astype(np.float64), ids, 20,
+                   rel_tol=1e-3 if use_gpu else 1e-5)
+    # reconstruct=True (the default): faiss's search_and_reconstruct triple
+    d2, i2, vec = index.search_mips_index(q.cuda(), 20)
+    assert np.array_equal(i2, idx) and np.array_equal(d2, dist)
+    assert vec.dtype == np.float32 and vec.shape == (10, 20, 768)
+    row_of = {int(p): r for r, p in enumerate(ids)}
+    want = np.stack([[rows[row_of[int(p)]].astype(np.float32) for p in line] for line in idx])
+    assert np.array_equal(vec, want)
+    # the returned vectors reproduce the returned distances
+    redo = np.einsum("qd,qkd->qk", q_seen.astype(np.float64), vec.astype(np.float64))
+    assert np.allclose(redo, dist, rtol=1e-3, atol=1e-4)
+    index.update_index()
+    d3, i3 = index.search_mips_index(q, 20, reconstruct=False)
+    assert np.array_equal(i3, idx)
+    index.reset_index()
+    d4, i4 = index.search_mips_index(q, 20, reconstruct=False)
+    assert np.array_equal(i4, idx)

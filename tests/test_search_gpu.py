@@ -320,6 +320,12 @@ def test_async_local_search_and_packed_merge(gu):
     assert int(gathered[:, 2 * 9 * k].abs().max().item()) == 0
     orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64),
                    ids, k, rel_tol=REL_TOL)
+    # merge_packed_sync: the same merge with the flag delivered through a pinned host word
+    s3, i3, f3 = MipsEngine.merge_packed_sync(gathered, 9, k, torch.float32)
+    assert f3 == 0 and torch.equal(i3, i) and torch.equal(s3, s)
+    gathered[2, 2 * 9 * k] = 1  # one list says "overflowed": the flag carries the OR
+    assert MipsEngine.merge_packed_sync(gathered, 9, k, torch.float32)[2] == 1
+    gathered[2, 2 * 9 * k] = 0
     # and it is the same answer as the blocking pair search_local + merge
     sl = torch.stack([e.search_local(0, q, k)[0] for e in engines])
     il = torch.stack([e.search_local(0, q, k)[1] for e in engines])
@@ -393,4 +399,35 @@ def test_queries_read_in_place_sliced_and_unaligned(gu):
     s, i = eng.search(big, 20, score_dtype=torch.float32)
     assert torch.equal(i, want_i) and eng.info()["last_scan_ms"] == timed
     eng.set_stats(True)
+    eng.close()
+
+
+def test_fetch_rows_and_unaligned_packed_tail(gu):
+    """artmips_fetch_rows returns stored rows as fp32 from whichever shard holds them; a packed
+    buffer whose status tail is not 8-byte aligned takes the copy path and gives the same list."""
+    from art_amd.engine import MipsEngine
+    rows, queries, ids = _random_case(5000, 5, 768, seed=41)
+    eng = gu.build_engine(rows, ids, devices=(0, 0, 0))  # three shards on the one GPU
+    pos = np.array([0, 4999, 1666, 1667, 3333, 3334, 17, 17], dtype=np.int64)
+    got = eng.fetch_rows(pos)
+    assert got.dtype == np.float32 and np.array_equal(got, rows[pos].astype(np.float32))
+    with pytest.raises(Exception):
+        eng.fetch_rows([5000])
+    eng.close()
+    eng = gu.build_engine(rows, ids)
+    q = torch.from_numpy(queries).cuda()
+    k = 11  # the tail starts 2*5*11 = 110 words in: 8-byte aligned iff the buffer itself is
+    words = MipsEngine.packed_words(5, k)
+    base = torch.empty(words + 3, dtype=torch.int32, device="cuda")
+    outs = []
+    for off in (0, 1):  # status raised in place, then (buffer 4 bytes off) copied behind the pipeline
+        buf = base[off:off + words]
+        eng.search_local_async(0, q, k, buf)
+        torch.cuda.synchronize()
+        outs.append(buf.clone())
+        assert int(buf[2 * 5 * k].item()) == 0
+    assert torch.equal(outs[0][:2 * 5 * k], outs[1][:2 * 5 * k])
+    s, i = eng.search_local(0, q, k)
+    assert torch.equal(outs[0][:5 * k].view(torch.float32).view(5, k), s)
+    assert torch.equal(outs[0][5 * k:2 * 5 * k].view(5, k), i)
     eng.close()
