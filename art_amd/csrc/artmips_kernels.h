@@ -878,8 +878,13 @@ struct SelectArgs {
     unsigned long long* cand_total;
 };
 
+// 32-bit scores radix-selected in LDS by select_kernel's "score route" (112 KiB, shared with skeys)
+constexpr int SCORE_MAX = 28672;
+
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
-    __shared__ __attribute__((aligned(16))) u64 skeys[SORT_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t big[SCORE_MAX];
+    static_assert(SCORE_MAX * 4 >= SORT_MAX * 8, "skeys lives in the same LDS as the scores");
+    u64* const skeys = (u64*)big;
     __shared__ __attribute__((aligned(16))) u64 sub[SUB_MAX];
     __shared__ int loff[MAX_LISTS + 1];
     __shared__ int hist[256];
@@ -926,31 +931,76 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         if (tid == 0) atomicOr(a.status, 2);
         return;
     }
-    // ---- balanced gather: candidate e of the query lives in the list found by binary search over
-    // the offsets; every thread handles M/nt candidates with independent loads.  The keys written
-    // here are pre-keys (score, row); passage ids are looked up only for the survivors.
-    u64* dst = in_lds ? skeys : gk;
-    {
-        // thread t takes candidates [t*cpt, t*cpt+cpt): one binary search, then a linear walk
-        const int cpt = (M + nt - 1) / nt;
-        int e = tid * cpt;
-        const int e_end = (e + cpt < M) ? e + cpt : M;
-        if (e < e_end) {
-            int lo = 0, hi = L;  // invariant: loff[lo] <= e < loff[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (loff[mid] <= e) lo = mid; else hi = mid;
-            }
-            for (; e < e_end; ++e) {
+    // list holding candidate e (binary search over the offsets): loff[lo] <= e < loff[lo + 1]
+    auto find_list = [&](int e) -> int {
+        int lo = 0, hi = L;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (loff[mid] <= e) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    // ---- balanced walk: thread t takes candidates [t*cpt, t*cpt+cpt), one binary search and then a
+    // linear walk over the lists; all loads are independent
+    const int cpt = (M + nt - 1) / nt;
+    const int e_begin = tid * cpt;
+    const int e_end = (e_begin + cpt < M) ? e_begin + cpt : M;
+    TopkScratch sc{skeys, sub, hist, ctl};
+    TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
+
+    // ---- score route (more candidates than the LDS sort holds, e.g. k = 1000): only the 32-bit
+    // scores go to LDS, the exact k-th best score is radix-selected there, and only the candidates at
+    // or above it (k of them, plus ties on that score) are fetched again, given their passage id and
+    // sorted.  Nothing is written to global memory.
+    if (!in_lds && M <= SCORE_MAX && a.k <= SUB_MAX) {
+        if (e_begin < e_end) {
+            int lo = find_list(e_begin);
+            for (int e = e_begin; e < e_end; ++e) {
                 while (loff[lo + 1] <= e) ++lo;
-                const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
-                dst[e] = ((u64)f2ord(__int_as_float(ent.x)) << 32) | (u64)(uint32_t)ent.y;
+                big[e] = f2ord(__int_as_float(a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])].x));
             }
+        }
+        __syncthreads();
+        const uint32_t kth = radix_kth<uint32_t>(big, M, a.k, hist, ctl);   // M > SORT_MAX >= k
+        if (tid == 0) ctl[2] = 0;
+        __syncthreads();
+        for (int e = tid; e < M; e += nt) {
+            if (big[e] >= kth) {
+                const int pos = atomicAdd(&ctl[2], 1);
+                if (pos < SUB_MAX) sub[pos] = (u64)e;
+            }
+        }
+        __syncthreads();
+        const int got = ctl[2];   // >= k; larger only when several rows score exactly the k-th best
+        if (got <= SUB_MAX) {
+            for (int i = tid; i < got; i += nt) {
+                const int e = (int)sub[i];
+                const int lo = find_list(e);
+                const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+                sub[i] = make_key(__int_as_float(ent.x), a.ids[ent.y]);
+            }
+            const int P = next_pow2(got < 2 ? 2 : got);
+            for (int i = got + tid; i < P; i += nt) sub[i] = 0ull;
+            __syncthreads();
+            bitonic_sort_desc<u64>(sub, P);
+            write_topk(sub, got, o);
+            return;
+        }
+        __syncthreads();   // massive ties on the k-th score: the general route below sorts them out
+    }
+
+    // ---- general routes: the keys written here are pre-keys (score, row); passage ids are looked
+    // up only for the survivors
+    u64* dst = in_lds ? skeys : gk;
+    if (e_begin < e_end) {
+        int lo = find_list(e_begin);
+        for (int e = e_begin; e < e_end; ++e) {
+            while (loff[lo + 1] <= e) ++lo;
+            const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+            dst[e] = ((u64)f2ord(__int_as_float(ent.x)) << 32) | (u64)(uint32_t)ent.y;
         }
     }
     __syncthreads();
-    TopkScratch sc{skeys, sub, hist, ctl};
-    TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
     topk_finish(dst, M, in_lds, a.ids, sc, o);
 }
 

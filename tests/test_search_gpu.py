@@ -167,6 +167,10 @@ def _random_case(n, q, dim, seed, scale=0.05):
     (30000, 16, 10, 128),
     (100000, 8, 1000, 768),  # large k: radix-select path in global memory
     (9000, 4, 2048, 768),    # k == ARTMIPS_MAX_K on a shard above SORT_MAX rows
+    (20000, 70, 1000, 768),  # 8,192 < candidates <= 28,672: scores radix-selected in LDS (score route)
+    (25000, 300, 1000, 768), # the same under the 8-wave x 2-group scan shape + a 44-query remainder
+    (28672, 3, 500, 128),    # exactly SCORE_MAX candidates
+    (28673, 3, 500, 128),    # one more: back to the radix select in global memory
 ])
 def test_random_vs_oracle(gu, n, q, k, dim):
     rows, queries, ids = _random_case(n, q, dim, seed=1000 + n + q + k)
@@ -430,4 +434,27 @@ def test_fetch_rows_and_unaligned_packed_tail(gu):
     s, i = eng.search_local(0, q, k)
     assert torch.equal(outs[0][:5 * k].view(torch.float32).view(5, k), s)
     assert torch.equal(outs[0][5 * k:2 * 5 * k].view(5, k), i)
+    eng.close()
+
+
+@pytest.mark.parametrize("span,k,route", [
+    (3, 1000, "score route, ties on the k-th score resolved by id"),
+    (1, 1900, "ties on the k-th score overflow the LDS sort: general route"),
+])
+def test_large_k_integer_ties_bit_exact(gu, span, k, route):
+    """Integer-valued embeddings (dot products exact in fp32 in any order) with far fewer distinct
+    scores than rows: many rows tie on the k-th best score, and the lower passage id must win, bit
+    for bit, through the LDS score route of select_kernel and through its fallback."""
+    n, q, dim = 20000, 5, 128
+    rng = np.random.Generator(np.random.PCG64(100 + span))
+    rows = rng.integers(-span, span + 1, size=(n, dim)).astype(np.float16)
+    queries = rng.integers(-span, span + 1, size=(q, dim)).astype(np.float16)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    es, ei, _ = orc.exact_topk(queries.astype(np.float64), rows.astype(np.float64), ids, k)
+    ties_at_kth = [(queries[j].astype(np.float64) @ rows.astype(np.float64).T == es[j, k - 1]).sum() for j in range(q)]
+    assert min(ties_at_kth) >= 10, "the case is meant to have many ties on the k-th score"
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s, es.astype(np.float32))
     eng.close()

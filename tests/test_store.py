@@ -143,3 +143,25 @@ def test_iter_chunks_and_detach(fx):
 def test_constructor_needs_path_outside_megatron(tmp_path):
     with pytest.raises(ValueError):
         OpenRetreivalDataStore(None, load_from_path=False)
+
+
+def test_constructor_reads_megatron_args_when_present(tmp_path, monkeypatch):
+    """Inside an ART process the store falls back to get_args().embedding_path / .rank when it is
+    built without a path (art_index.py:20-23) and its progress lines are printed only where
+    mpu says so (art_index.py:47,53)."""
+    import sys
+    import types
+    from art_amd.art_index import OpenRetreivalDataStore
+
+    args = types.SimpleNamespace(embedding_path=str(tmp_path / "wiki.pkl"), rank=3)
+    mpu = types.SimpleNamespace(is_unitialized=lambda: False, get_data_parallel_rank=lambda: 1)
+    fake = types.ModuleType("megatron")
+    fake.get_args = lambda: args
+    fake.mpu = mpu
+    monkeypatch.setitem(sys.modules, "megatron", fake)
+    store = OpenRetreivalDataStore(load_from_path=False)
+    assert store.embedding_path == args.embedding_path and store.rank == 3
+    assert store.temp_dir_name == str(tmp_path / "wiki_tmp")
+    store.add_block_data(np.array([5, 6]), np.ones((2, 4), dtype=np.float32))
+    store.save_shard()
+    assert os.path.exists(os.path.join(store.temp_dir_name, "3.pkl"))
