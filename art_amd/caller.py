@@ -12,6 +12,8 @@ its ``torch.split(...)[local_rank]`` line: this rank's rows of ``distance`` (fp1
 import torch
 import torch.distributed as dist
 
+from .distributed import all_gather_rows
+
 
 def _world(group):
     return dist.get_world_size(group) if dist.is_initialized() else 1
@@ -29,10 +31,7 @@ def gather_queries(query_tensor, group=None):
     if world == 1:
         return q
     out = torch.empty((world * q.shape[0],) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, q, group=group)
-    else:
-        dist.all_gather(list(out.split(q.shape[0], dim=0)), q, group=group)
+    all_gather_rows(out.view((world,) + tuple(q.shape)), q, group)
     return out
 
 
@@ -45,15 +44,15 @@ def varsize_gather_nograd(x, group=None):
     if world == 1:
         return x, [int(x.shape[0])]
     size = torch.tensor([x.shape[0]], device=x.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size, group=group)
-    allsizes = [int(s.item()) for s in sizes]
+    sizes = torch.zeros((world, 1), device=x.device, dtype=torch.int64)
+    all_gather_rows(sizes, size, group)
+    allsizes = [int(v) for v in sizes.view(-1).tolist()]
     max_size = max(allsizes)
     padded = torch.zeros((max_size,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     padded[:x.shape[0]] = x
-    pieces = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(pieces, padded, group=group)
-    return torch.cat([p[:n] for p, n in zip(pieces, allsizes)], dim=0), allsizes
+    pieces = torch.empty((world,) + tuple(padded.shape), dtype=x.dtype, device=x.device)
+    all_gather_rows(pieces, padded, group)
+    return torch.cat([pieces[r, :n] for r, n in enumerate(allsizes)], dim=0), allsizes
 
 
 def spmd_get_topk(searcher, query_tensor, topk, group=None):

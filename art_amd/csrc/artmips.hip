@@ -17,6 +17,7 @@
 #include <mutex>
 #include <new>
 #include <vector>
+#include <unistd.h>
 
 using namespace artk;
 
@@ -602,6 +603,25 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     return p;
 }
 
+// ARTMIPS_DEBUG_SYNC=1 (diagnostics): wait for every kernel of the pipeline and say so on stderr, so
+// that a kernel that never ends can be named.
+static bool debug_sync() {
+    static const bool on = [] { const char* e = getenv("ARTMIPS_DEBUG_SYNC"); return e && atoi(e) != 0; }();
+    return on;
+}
+#define DEBUG_STEP(st, ...)                                            \
+    do {                                                               \
+        if (debug_sync()) {                                            \
+            fprintf(stderr, "[artmips %d] ", (int)getpid());           \
+            fprintf(stderr, __VA_ARGS__);                              \
+            fprintf(stderr, " ...");                                   \
+            fflush(stderr);                                            \
+            hipError_t e__ = hipStreamSynchronize(st);                 \
+            fprintf(stderr, " %s\n", hipGetErrorString(e__));          \
+            fflush(stderr);                                            \
+        }                                                              \
+    } while (0)
+
 template <typename T>
 static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int dim, void* out,
                         hipStream_t st) {
@@ -625,6 +645,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
         else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
         HIP_TRY(hipGetLastError());
+        DEBUG_STEP(st, "pack q_count=%d qt=%d", q_count, qt);
         q_src = s.qpad.p;
         q_rows = qt;
     }
@@ -647,15 +668,19 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         a.tile_stride = p.sample_stride;
         int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
+        DEBUG_STEP(st, "scan<GROUPMAX> grid=%d nq=%d nw=%d n_work=%lld stride=%lld", p.grid0, p.nq, p.nw,
+                   a.n_work, a.tile_stride);
         size_t kth_lds = 8;
         while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
         const int kth_threads = (p.grid0 * 4 <= 4096) ? 256 : SEL_THREADS;
         hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
                            (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p, clear);
         HIP_TRY(hipGetLastError());
+        DEBUG_STEP(st, "kth grid=%d threads=%d", qt, kth_threads);
     } else {
         hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, (float*)s.thr.p, q_count, qt, clear);
         HIP_TRY(hipGetLastError());
+        DEBUG_STEP(st, "fill_thr q_count=%d qt=%d", q_count, qt);
     }
 
     a.n_work = p.n_tiles;
@@ -672,6 +697,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid, st);
     if (rc) return rc;
     if (timed) HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
+    DEBUG_STEP(st, "scan<FILTER> grid=%d nq=%d nw=%d stg=%d cap=%d tiles=%lld rows=%lld q_count=%d q_rows=%d",
+               p.grid, p.nq, p.nw, (int)p.stage_lds, p.cap, p.n_tiles, (long long)gen.n_rows, q_count, q_rows);
 
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -695,6 +722,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     const int sel_threads = (k <= 128 && p.pass0) ? 256 : SEL_THREADS;
     hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(sel_threads), 0, st, sa);
     HIP_TRY(hipGetLastError());
+    DEBUG_STEP(st, "select grid=%d threads=%d k=%d", q_count, sel_threads, k);
     return 0;
 }
 
@@ -897,6 +925,7 @@ static int run_merge(int device, const float* scores, const int32_t* ids, int n_
     m.status = (int*)status_buf->p;
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n_q), dim3(SEL_THREADS), 0, st, m);
     HIP_TRY(hipGetLastError());
+    DEBUG_STEP(st, "merge n_q=%lld lists=%d k=%d", (long long)n_q, n_lists, k);
     return 0;
 }
 

@@ -21,6 +21,24 @@ def shard_bounds(n_rows, world_size):
     return [(min(chunk * r, n_rows), min(chunk * (r + 1), n_rows)) for r in range(world_size)]
 
 
+def all_gather_rows(out, inp, group=None, async_op=False):
+    """All-gather equal-size contiguous tensors: out [world, *inp.shape] <- every rank's inp.
+
+    "nccl" (RCCL over xGMI) gathers device buffers in place, one collective.  Any other backend is a
+    test backend here (gloo: CPU tests, or several ranks sharing the one GPU of the test box) and is
+    kept away from device memory: the payload is staged through host tensors explicitly, because
+    gloo's own CUDA-tensor path intermittently deadlocks when two processes share a GPU (seen on the
+    MI355X test box with nothing but torch.zeros + dist.all_gather in the loop)."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    world = dist.get_world_size(group)
+    host = inp.detach().cpu().contiguous()
+    pieces = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(pieces, host, group=group)
+    out.copy_(torch.stack(pieces, dim=0).view(out.shape))
+    return None
+
+
 def exchange_candidates(scores, ids, group=None):
     """All-gather per-rank [Q, k] (fp32 score, int32 id) lists into [world, Q, k] pairs with a
     single collective: the two arrays travel as one int32 tensor [Q, k, 2]."""
@@ -28,9 +46,8 @@ def exchange_candidates(scores, ids, group=None):
     if world == 1:
         return scores.unsqueeze(0), ids.unsqueeze(0)
     packed = torch.stack((scores.contiguous().view(torch.int32), ids), dim=-1).contiguous()
-    gathered = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(gathered, packed, group=group)
-    allp = torch.stack(gathered, dim=0)
+    allp = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    all_gather_rows(allp, packed, group)
     return allp[..., 0].contiguous().view(torch.float32), allp[..., 1].contiguous()
 
 
@@ -61,7 +78,10 @@ class SpmdSearcher(object):
     step, so the ranks never disagree about the number of collectives.
     Buffers are cached per (Q, k): the steady state allocates only the two result tensors."""
 
-    def __init__(self, engine, group=None, always_gather=False):
+    def __init__(self, engine, group=None, always_gather=False, chunk_queries=2048):
+        if chunk_queries < 256 or chunk_queries % 256:
+            raise ValueError("chunk_queries must be a positive multiple of 256 (queries per index sweep)")
+        self.chunk_queries = int(chunk_queries)
         self.engine = engine
         self.group = group
         self.always_gather = always_gather  # run the collective even with one rank (measurements)
@@ -94,23 +114,72 @@ class SpmdSearcher(object):
             self._nccl = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         world = self._world
         n_q = queries.shape[0]
+        if n_q > self.chunk_queries and (world > 1 or self.always_gather):
+            return self._search_pipelined(queries, int(top_k), score_dtype)
         local, gathered = self._buffers(n_q, int(top_k), world, queries.device)
         self.last_retries = 0
         while True:
             self.engine.search_local_async(0, queries, top_k, local)
             if world > 1 or self.always_gather:
-                if self._nccl:
-                    dist.all_gather_into_tensor(gathered, local, group=self.group)
-                else:  # gloo (tests): the rows of `gathered` are contiguous views
-                    dist.all_gather(list(gathered.unbind(0)), local, group=self.group)
+                self._all_gather(gathered, local)
             # the step's only host wait: the merge writes the flag into a pinned host word and the
             # stream is synchronised inside the call (no device-to-host copy behind the merge)
             s, i, status = MipsEngine.merge_packed_sync(gathered, n_q, top_k, score_dtype)
-            out = (s, i)
             if status & 2:
                 raise RuntimeError("artmips: internal key scratch too small on some rank")
             if not (status & 1):
-                return out
+                return s, i
+            self.engine.grow_lists()
+            self.last_retries += 1
+
+    def _all_gather(self, gathered, local, async_op=False):
+        return all_gather_rows(gathered, local, self.group, async_op=async_op and self._nccl)
+
+    def _search_pipelined(self, queries, top_k, score_dtype):
+        """Large batches (evaluation sets, BASELINE configs 3 and 4): the queries are cut into chunks
+        of `chunk_queries` (a multiple of the 256 queries one sweep of the shard scores), and the
+        all-gather of chunk c runs on RCCL's stream while the scan of chunk c+1 runs on the search
+        stream, so only the last chunk's exchange is exposed (at 16,384 x top-1000 every rank
+        receives 131 MB from each peer: milliseconds over xGMI against ~10 ms of scan per chunk).
+        The merges follow in stream order; one overflow flag per chunk, ORed."""
+        from .engine import MipsEngine
+
+        world = self._world
+        n_q = queries.shape[0]
+        bounds = [(q0, min(q0 + self.chunk_queries, n_q)) for q0 in range(0, n_q, self.chunk_queries)]
+        dev = queries.device
+        key = ("pipe", n_q, top_k, world)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            if len(self._bufs) >= 8:
+                self._bufs.clear()
+            bufs = []
+            for q0, q1 in bounds:
+                words = MipsEngine.packed_words(q1 - q0, top_k)
+                bufs.append((torch.empty((words,), dtype=torch.int32, device=dev),
+                             torch.empty((world, words), dtype=torch.int32, device=dev)))
+            self._bufs[key] = bufs
+        out_s = torch.empty((n_q, top_k), dtype=score_dtype, device=dev)
+        out_i = torch.empty((n_q, top_k), dtype=torch.int32, device=dev)
+        self.last_retries = 0
+        while True:
+            works = []
+            for (q0, q1), (local, gathered) in zip(bounds, bufs):
+                self.engine.search_local_async(0, queries[q0:q1], top_k, local)
+                works.append(self._all_gather(gathered, local, async_op=True))
+            status = 0
+            for (q0, q1), (local, gathered), work in zip(bounds, bufs, works):
+                if work is not None:
+                    work.wait()  # the search stream waits for the collective; the host does not
+                s, i, st = MipsEngine.merge_packed_sync(gathered, q1 - q0, top_k, score_dtype)
+                out_s[q0:q1] = s
+                out_i[q0:q1] = i
+                status |= st
+            if status & 2:
+                raise RuntimeError("artmips: internal key scratch too small on some rank")
+            if not (status & 1):
+                torch.cuda.current_stream(dev).synchronize()
+                return out_s, out_i
             self.engine.grow_lists()
             self.last_retries += 1
 

@@ -281,6 +281,14 @@ def test_spmd_search_world1_nccl(gu):
         s, i = engine_spmd_search(eng, torch.from_numpy(queries).cuda(), 20, score_dtype=torch.float32)
         orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64),
                        ids, 20, rel_tol=REL_TOL)
+        # large batch: chunked, with the (RCCL, asynchronous) all-gather of one chunk behind the next
+        # chunk's scan, against the one-exchange step
+        from art_amd.distributed import SpmdSearcher
+        rows, queries, ids = _random_case(5000, 600, 768, seed=78)
+        big = torch.from_numpy(queries).cuda()
+        s1, i1 = SpmdSearcher(eng, always_gather=True, chunk_queries=256).search(big, 20, score_dtype=torch.float32)
+        s2, i2 = SpmdSearcher(eng, always_gather=True).search(big, 20, score_dtype=torch.float32)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
         eng.close()
     finally:
         if created:

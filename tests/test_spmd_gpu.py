@@ -2,7 +2,9 @@
 each owns half of the rows in its own MipsEngine, candidates travel through torch.distributed
 (gloo here: RCCL refuses two ranks on one device; the driver's multi-GPU bench uses "nccl"), and
 every rank merges on the device.  Compared with the golden fixture and the oracle."""
+import faulthandler
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _worker(rank, world, port, out_dir):
+    faulthandler.dump_traceback_later(90, exit=True, file=sys.stderr)  # a stuck rank says where
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,6 +55,7 @@ def test_spmd_two_ranks_one_gpu(tmp_path, world):
 
 
 def _caller_worker(rank, world, port, out_dir):
+    faulthandler.dump_traceback_later(90, exit=True, file=sys.stderr)  # a stuck rank says where
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -97,3 +101,50 @@ def test_caller_protocol_spmd_on_gpu(tmp_path, world):
                                    rtol=2e-3)  # fp16 output rounding
         off = sum(sizes[:r])
         np.testing.assert_array_equal(np.load(tmp_path / ("e%d.npy" % r)), fx["ids_k100"][off:off + sizes[r]])
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    faulthandler.dump_traceback_later(90, exit=True, file=sys.stderr)  # a stuck rank says where
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd.distributed import SpmdSearcher, shard_bounds
+        from art_amd.engine import MipsEngine
+        torch.cuda.set_device(0)
+        rng = np.random.Generator(np.random.PCG64(77))
+        rows = (rng.standard_normal((9001, 768)) * 0.05).astype(np.float16)
+        ids = (rng.permutation(9001) + 1).astype(np.int32)
+        queries = rng.standard_normal((700, 768)).astype(np.float16)
+        lo, hi = shard_bounds(9001, world)[rank]
+        eng = MipsEngine(768, torch.float16, [0])
+        eng.build(rows[lo:hi], ids[lo:hi])
+        q = torch.from_numpy(queries).cuda()
+        # 700 queries in chunks of 256 (256 + 256 + 188): per-chunk exchange and merge ...
+        s1, i1 = SpmdSearcher(eng, chunk_queries=256).search(q, 20, score_dtype=torch.float32)
+        # ... against one exchange for the whole batch
+        s2, i2 = SpmdSearcher(eng, chunk_queries=2048).search(q, 20, score_dtype=torch.float32)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+        np.save(os.path.join(out_dir, "pi_%d.npy" % rank), i1.cpu().numpy())
+        np.save(os.path.join(out_dir, "ps_%d.npy" % rank), s1.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spmd_pipelined_large_batch(tmp_path):
+    """The chunked large-batch step (exchange of chunk c behind the scan of chunk c+1) gives every
+    rank the result of the one-exchange step and of the oracle."""
+    from oracle import mips_oracle as orc
+    world = 2
+    port = 29000 + (os.getpid() % 300)
+    mp.spawn(_pipelined_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.Generator(np.random.PCG64(77))
+    rows = (rng.standard_normal((9001, 768)) * 0.05).astype(np.float16)
+    ids = (rng.permutation(9001) + 1).astype(np.int32)
+    queries = rng.standard_normal((700, 768)).astype(np.float16)
+    i0 = np.load(tmp_path / "pi_0.npy")
+    np.testing.assert_array_equal(i0, np.load(tmp_path / "pi_1.npy"))
+    n_diff = orc.check_topk(np.load(tmp_path / "ps_0.npy"), i0, queries.astype(np.float64),
+                            rows.astype(np.float64), ids, 20, rel_tol=1e-3)
+    assert n_diff <= 28
