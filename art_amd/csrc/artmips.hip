@@ -142,10 +142,14 @@ static void free_generation(Generation& g) {
 // ---------------------------------------------------------------------------------------------
 // kernel launch tables
 // ---------------------------------------------------------------------------------------------
+// mode: MODE_FILTER, MODE_GROUPMAX, or MODE_GROUPMAX4 (pass 0 keeping four values per lane; built
+// where large k occurs: 2-byte storage, dim 768)
+enum { MODE_GROUPMAX4 = 2 };
+
 template <typename T, int DIM, int NSTAGE, int AUX, int NQ = 1, int STG = 1, int NW = 4>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
-    static bool attr_done[ARTMIPS_MAX_DEVICES * 4][2] = {};
+    static bool attr_done[ARTMIPS_MAX_DEVICES * 4][3] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
@@ -157,6 +161,18 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
             attr_done[dev][0] = true;
         }
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+    } else if (mode == MODE_GROUPMAX4) {
+        if constexpr (DIM == 768 && sizeof(T) == 2 && STG == 0) {
+            auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW, 4>;
+            if (!attr_done[dev][2]) {
+                HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds));
+                attr_done[dev][2] = true;
+            }
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+        } else {
+            return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: no top-4 pass 0 for this shape");
+        }
     } else {
         auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW>;
         if (!attr_done[dev][1]) {
@@ -539,6 +555,7 @@ struct Plan {
     int nq;               // column groups per scan pass
     int nw;               // waves per scan workgroup (4 or 8); a column group is 16*nw queries
     bool stage_lds;       // stage survivors in LDS (few per lane) instead of storing them directly
+    int topt;             // sample values each pass-0 lane keeps per query (1, or 4 for large k)
 };
 
 static int round_up_pow2(long long x) {
@@ -547,10 +564,16 @@ static int round_up_pow2(long long x) {
     return (int)std::min<long long>(p, 1ll << 30);
 }
 
-static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, int cap_boost, int nq, int nw) {
+static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, int cap_boost, int nq, int nw,
+                      bool top4_built) {
     Plan p;
     p.nq = nq;
     p.nw = nw;
+    // Large k wants 8k sample values per query.  One per lane means thousands of pass-0 workgroups,
+    // each reloading the whole query operand (384 KiB at 256 queries) for a handful of tiles; four per
+    // lane reach the same count with a quarter of the workgroups.
+    p.topt = (top4_built && k > 128) ? 4 : 1;
+    if (const char* e = getenv("ARTMIPS_TOPT")) p.topt = (atoi(e) == 4 && top4_built) ? 4 : 1;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     int grid_mult = 1;
     if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
@@ -562,7 +585,8 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     // (so that the k-th largest group maximum is close to the k-th best of the sample) and a sample
     // of about 1/128 of the rows, but never more than 1/4 of them.
     long long groups = std::max<long long>(1024, 8ll * k);
-    long long grid0 = std::min<long long>((groups + 3) / 4, 8192);
+    const long long per_wg = 4ll * p.topt;  // sample values one pass-0 workgroup contributes per query
+    long long grid0 = std::min<long long>(std::max<long long>(256, (groups + per_wg - 1) / per_wg), 8192);
     // sample = n_tiles / sample_div.  Pass 0 costs scan_time / sample_div; every survivor of the
     // filter costs scan time (a wave that keeps one holds its workgroup at the next barrier) and
     // select time, and the expected survivors per query are k * sample_div whatever the shard size.
@@ -576,7 +600,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     sample_div = std::min<long long>(128, std::max<long long>(16, sample_div));
     if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
     long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
-    p.pass0 = (grid0 * 4 >= k) && (sample * 4 <= p.n_tiles);
+    p.pass0 = (grid0 * per_wg >= k) && (sample * 4 <= p.n_tiles);
     if (p.pass0) {
         const long long t0 = std::max<long long>(1, sample / grid0);
         p.grid0 = (int)grid0;
@@ -666,15 +690,18 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     if (p.pass0) {
         a.n_work = p.n_sample;
         a.tile_stride = p.sample_stride;
-        int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
+        int rc = (p.topt == 4)
+            ? launch_scan(h->dtype, h->dim, p.nq, p.nw, false, MODE_GROUPMAX4, a, p.grid0, st)
+            : launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
         if (rc) return rc;
-        DEBUG_STEP(st, "scan<GROUPMAX> grid=%d nq=%d nw=%d n_work=%lld stride=%lld", p.grid0, p.nq, p.nw,
-                   a.n_work, a.tile_stride);
+        DEBUG_STEP(st, "scan<GROUPMAX> grid=%d nq=%d nw=%d topt=%d n_work=%lld stride=%lld", p.grid0, p.nq,
+                   p.nw, p.topt, a.n_work, a.tile_stride);
+        const int n_values = p.grid0 * 4 * p.topt;
         size_t kth_lds = 8;
-        while (kth_lds < (size_t)p.grid0 * 4) kth_lds <<= 1;
-        const int kth_threads = (p.grid0 * 4 <= 4096) ? 256 : SEL_THREADS;
+        while (kth_lds < (size_t)n_values) kth_lds <<= 1;
+        const int kth_threads = (n_values <= 4096) ? 256 : SEL_THREADS;
         hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
-                           (const float*)s.gmax.p, p.grid0, p.nq, k, q_count, (float*)s.thr.p, clear);
+                           (const float*)s.gmax.p, n_values, p.nq, k, q_count, (float*)s.thr.p, clear);
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "kth grid=%d threads=%d", qt, kth_threads);
     } else {
@@ -775,12 +802,13 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     const int QT = nq * nw * 16;
     const int NT = nw * 64;
     c.t_begin = std::chrono::steady_clock::now();
-    Plan p = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq, nw);
+    Plan p = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq, nw,
+                       h->dim == 768 && h->dtype != ARTMIPS_F32);
     int rc = 0;
     if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
     if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
     if ((rc = ensure(s.status, 64))) return rc;
-    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * NT * 4))) return rc;
+    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * NT * 4 * p.topt))) return rc;
     if ((rc = ensure(s.counts, (size_t)p.grid * nq * NT * 4))) return rc;
     const size_t list_entries = (size_t)p.grid * nq * NT * (size_t)p.cap;
     if ((rc = ensure(s.lists, list_entries * 8))) return rc;

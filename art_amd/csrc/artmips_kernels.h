@@ -339,7 +339,11 @@ __device__ __forceinline__ void settle_queries(V (*bq)[KSTEPS]) {
 // NW = 8 puts two waves on every SIMD: while one issues its LDS-DMA pieces or waits for LDS, the
 // other keeps the matrix pipe busy (profiles/r01_k_pmc_sq_counters.json: with one wave per SIMD the
 // pipe idles 55 % of the time at 256 queries per sweep).
-template <typename T, int DIM, int NSTAGE, int MODE, int AUX, int NQ, int STG = 1, int NW = 4>
+// TOPT (GROUPMAX only): sample scores each lane keeps per query.  1 = its maximum; 4 = its four best,
+// which lets pass 0 reach the same number of sample values per query with a quarter of the
+// workgroups (used for large k, where the value count 8k makes pass 0 launch thousands of workgroups
+// that each reload the whole query operand).
+template <typename T, int DIM, int NSTAGE, int MODE, int AUX, int NQ, int STG = 1, int NW = 4, int TOPT = 1>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     typedef typename Elem<T>::V V;
     constexpr int ES = (int)sizeof(T);     // bytes per stored element
@@ -443,10 +447,15 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         }
     };
 
+    static_assert(TOPT == 1 || MODE == MODE_GROUPMAX, "TOPT belongs to pass 0");
     int cnt[NQ];
-    float gm[NQ];
+    float gm[NQ][TOPT];   // descending
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) { cnt[j] = 0; gm[j] = -INFINITY; }
+    for (int j = 0; j < NQ; ++j) {
+        cnt[j] = 0;
+#pragma unroll
+        for (int t = 0; t < TOPT; ++t) gm[j][t] = -INFINITY;
+    }
     // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
     int2* const my_list = (MODE == MODE_FILTER)
         ? a.lists + ((size_t)b * NQ * NT + tid) * (size_t)a.cap : nullptr;
@@ -558,7 +567,14 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const long long row = row_base + i;
-                            if (row < n_rows) gm[j] = fmaxf(gm[j], acc[j][i]);
+                            // insertion into the lane's descending top-TOPT (NaN never enters)
+                            float x = (row < n_rows) ? acc[j][i] : -INFINITY;
+#pragma unroll
+                            for (int t = 0; t < TOPT; ++t) {
+                                const float hi = fmaxf(gm[j][t], x);
+                                x = fminf(gm[j][t], x);
+                                gm[j][t] = hi;
+                            }
                         }
                     }
                 }
@@ -578,8 +594,12 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const size_t o = (size_t)(j * QG + w * 16 + r) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
-        if (MODE == MODE_FILTER) a.counts[o] = cnt[j];
-        else a.gmax[o] = gm[j];
+        if (MODE == MODE_FILTER) {
+            a.counts[o] = cnt[j];
+        } else {  // [query][(workgroup*4 + lane group)*TOPT + t]
+#pragma unroll
+            for (int t = 0; t < TOPT; ++t) a.gmax[o * TOPT + t] = gm[j][t];
+        }
     }
 }
 
@@ -696,13 +716,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// kth_kernel (pass 0): tau[q] = k-th largest of the per-lane maxima that belong to query q.
-// Each maximum is the score of a distinct row, so k of them >= tau proves that the k-th best
+// kth_kernel (pass 0): tau[q] = k-th largest of the per-lane sample values (the lane's maximum, or
+// its four best) that belong to query q.  Each value is the score of a distinct row, so k of them >= tau proves that the k-th best
 // score over the whole shard is >= tau: dropping every score < tau loses no top-k member.
 // One block per query slot (64 blocks); dynamic LDS = next_pow2(n_groups) * 4 bytes.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restrict__ gmax,
-                                                          int scan_grid, int nq, int k, int q_count,
+                                                          int n_values, int nq, int k, int q_count,
                                                           float* __restrict__ thr,
                                                           int* __restrict__ status_to_clear) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -711,7 +731,7 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
     __shared__ int ctl[4];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const int G = scan_grid * 4;
+    const int G = n_values;  // pass-0 workgroups * 4 lane groups * values kept per lane
     // first query tile of a search: clear the 4 status words (flags, pad, 64-bit candidate count) the
     // select raises; they may be the status tail of a packed candidate list, which is 4 words long
     if (status_to_clear != nullptr && q == 0 && tid < 4) status_to_clear[tid] = 0;
