@@ -22,6 +22,9 @@
  *     artmips_merge, artmips_merge_packed and artmips_search_local_async do not.
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
  *   - passage ids are int32 (the reference returns int32: art_index.py:297).
+ *   - a handle is used by one thread at a time (the reference drives its index from one
+ *     Python thread of one process per node: art_model.py:327,351); different handles are
+ *     independent, and the handle-less merges serialise per process on an internal lock.
  *   - top-k order: score descending, ties broken by LOWER passage id
  *     (BASELINE.json north_star); scores are fp32-accumulated dot products.
  */
