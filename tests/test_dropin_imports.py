@@ -22,6 +22,15 @@ def test_shim_module_satisfies_the_callers_import_lines(tmp_path, monkeypatch):
     monkeypatch.syspath_prepend(str(tmp_path))
     for name in [m for m in sys.modules if m == "megatron" or m.startswith("megatron.")]:
         monkeypatch.delitem(sys.modules, name)
+    try:
+        _check(monkeypatch)
+    finally:  # the stand-in package must not outlive this test
+        for name in [m for m in sys.modules if m == "megatron" or m.startswith("megatron.")]:
+            del sys.modules[name]
+        importlib.invalidate_caches()
+
+
+def _check(monkeypatch):
     ns = {}
     exec("from megatron.data.art_index import detach, OpenRetreivalDataStore", ns)                    # indexer.py:7
     exec("from megatron.data.art_index import OpenRetreivalDataStore, DistributedBruteForceIndex", ns)  # art_model.py:12
@@ -44,4 +53,3 @@ def test_shim_module_satisfies_the_callers_import_lines(tmp_path, monkeypatch):
     # inside "megatron" the store takes its path and rank from get_args() (art_index.py:20-23)
     store = store_cls(load_from_path=False)
     assert store.embedding_path == "/nonexistent/evidence.pkl" and store.rank == 0
-    importlib.invalidate_caches()
