@@ -35,9 +35,23 @@ def run(tag, eng, q, k, chunk=None, reps=2):
     dt = (time.perf_counter() - t0) / reps
     info = eng.info()
     flops = 2.0 * q.shape[0] * n_rows * 768
+    roof = None
+    if chunk is None:
+        # SURVEY.md §8(d), MFMA-bound regime: both fractions for the scan kernels of the last call
+        # (HIP events on the launch stream, summed over the sweeps): flops / t against the dense MFMA
+        # peak, and the HBM traffic of ceil(Q/256) sweeps against the HBM peak
+        scan_s = info["last_scan_ms"] * 1e-3
+        sweeps = info["last_scan_launches"]
+        elem = 2
+        roof = {"bound": "mfma", "kernel": "scan_kernel<FILTER>, %d sweeps" % sweeps,
+                "kernel_s_total": scan_s, "achieved": flops / scan_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": flops / scan_s / 2.5e15,
+                "hbm_achieved_GBs": sweeps * n_rows * 768 * elem / scan_s / 1e9,
+                "hbm_frac": sweeps * n_rows * 768 * elem / scan_s / 8e12,
+                "scan_share_of_call": scan_s / dt}
     print(json.dumps({"config": tag, "queries": q.shape[0], "top_k": k, "rows": n_rows, "chunk": chunk,
                       "seconds_per_pass": dt, "queries_per_s": q.shape[0] / dt, "tflops": flops / dt / 1e12,
-                      "frac_of_2.5PF": flops / dt / 2.5e15,
+                      "frac_of_2.5PF": flops / dt / 2.5e15, "roofline": roof,
                       "index_sweeps": info["last_scan_launches"] if chunk is None else None,
                       "candidates_per_query": info["last_candidates"] / (q.shape[0] if chunk is None else min(chunk, q.shape[0])),
                       "retries": info["last_retries"]}), flush=True)
