@@ -33,6 +33,8 @@ SYMBOLS = (
     "artmips_merge_packed",
     "artmips_merge_packed_sync",
     "artmips_fetch_rows",
+    "artmips_generation",
+    "artmips_download",
     "artmips_grow_lists",
     "artmips_set_stats",
     "artmips_info",
@@ -108,6 +110,10 @@ def _load():
     lib.artmips_merge_packed_sync.restype = i32
     lib.artmips_fetch_rows.argtypes = [vp, vp, i64, vp]
     lib.artmips_fetch_rows.restype = i32
+    lib.artmips_generation.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.artmips_generation.restype = i32
+    lib.artmips_download.argtypes = [vp, ctypes.c_uint64, i64, i64, vp, vp]
+    lib.artmips_download.restype = i32
     lib.artmips_grow_lists.argtypes = [vp]
     lib.artmips_grow_lists.restype = i32
     lib.artmips_set_stats.argtypes = [vp, i32]

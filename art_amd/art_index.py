@@ -280,6 +280,55 @@ class DistributedBruteForceIndex(object):
         self.indices_arr = np.asarray(flat.ids).astype(np.int64)
         self.id_map = _IdMap(self.indices_arr)
 
+    def save_flat(self, path, background=False):
+        """Write the live index to `path` as an art_amd.flat_store file (streamed off the GPUs, ids
+        ascending).  With background=True the export runs on a thread beside the searches and the
+        Thread object is returned (join it before the process exits; a refresh that replaces the
+        index meanwhile makes the export fail cleanly, its error is kept in thread.error).  Not in
+        the reference, whose index has no way back to the disk: its checkpoint is the pickle the
+        indexer wrote (indexer.py:156-163), which the device refresh path never writes."""
+        from .flat_store import save_engine_flat
+
+        if self.evidence_embeds is None:
+            raise RuntimeError("MIPS index is empty: nothing to save")
+        engine = self.evidence_embeds
+        if not background:
+            return save_engine_flat(engine, path)
+        import threading
+
+        def run():
+            try:
+                t.rows_written = save_engine_flat(engine, path)
+            except Exception as e:  # noqa: BLE001 - reported through the thread object
+                t.error = e
+
+        t = threading.Thread(target=run, name="artmips-save-flat", daemon=False)
+        t.error = None
+        t.rows_written = 0
+        t.start()
+        return t
+
+    def to_store(self, embedding_path=None, rank=0):
+        """The live index as a reference-format store object (dict {numpy.int64 id -> float16[dim]}
+        in row order), e.g. to write the reference's pickle with save_shard()/merge_shards_and_save()
+        or pickle.dump(store.state()).  One Python object per row: meant for modest sizes and for
+        compatibility, the flat file is the fast artefact."""
+        if self.evidence_embeds is None:
+            raise RuntimeError("MIPS index is empty: nothing to export")
+        if self.storage_dtype != torch.float16:
+            raise ValueError("the reference store holds float16 rows")
+        engine = self.evidence_embeds
+        path = embedding_path
+        if path is None and self.embed_data is not None:
+            path = self.embed_data.embedding_path
+        store = OpenRetreivalDataStore(path, load_from_path=False, rank=rank)
+        gen = engine.generation()
+        step = 1 << 16
+        for lo in range(0, int(engine.n_rows), step):
+            rows, ids = engine.download(lo, min(step, int(engine.n_rows) - lo), gen)
+            store.add_block_data(ids.astype(np.int64), rows)
+        return store
+
     def search_mips_index(self, query_embeds, top_k, reconstruct=True):
         """Top-k passages by inner product.
 

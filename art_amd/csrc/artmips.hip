@@ -94,6 +94,13 @@ struct artmips {
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
+    // artmips_download: its own pinned staging and streams, so that it can run beside searches; the
+    // mutex orders it against the generation swap of artmips_finalize / artmips_destroy
+    std::mutex gen_mutex;
+    uint64_t generation = 0;
+    void* dl_pin[2] = {nullptr, nullptr};
+    size_t dl_pin_bytes = 0;
+    hipStream_t dl_stream[ARTMIPS_MAX_DEVICES] = {};
     // gather buffers on slot 0 for the multi-shard merge
     DevBuf g_scores, g_ids, m_keys, m_status;
     // stats
@@ -323,7 +330,13 @@ extern "C" void artmips_destroy(artmips_t* h) {
         for (int i = 0; i < 2; ++i) {
             if (h->pin[i]) (void)hipHostFree(h->pin[i]);
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
+            if (h->dl_pin[i]) (void)hipHostFree(h->dl_pin[i]);
         }
+    }
+    for (int i = 0; i < h->n_dev; ++i) {
+        if (!h->dl_stream[i]) continue;
+        DeviceGuard g(h->sh[i].dev);
+        (void)hipStreamDestroy(h->dl_stream[i]);
     }
     delete h;
 }
@@ -526,6 +539,8 @@ extern "C" int artmips_finalize(artmips_t* h) {
     }
     if (dups) return fail(ARTMIPS_ERR_STATE, "Unexpectedly tried to overwrite block data: %llu rows were uploaded twice", dups);
     if (missing) return fail(ARTMIPS_ERR_STATE, "%llu of %lld rows were never uploaded", missing, (long long)h->next_total);
+    std::lock_guard<std::mutex> swap_lock(h->gen_mutex);  // no artmips_download chunk is in flight
+    ++h->generation;
     for (int i = 0; i < h->n_dev; ++i) {
         Shard& s = h->sh[i];
         DeviceGuard g(s.dev);
@@ -1205,6 +1220,61 @@ extern "C" int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_
         if (e != hipSuccess) return fail(ARTMIPS_ERR_HIP, "row fetch on shard %d failed: %s", sidx, hipGetErrorString(e));
         for (size_t j = 0; j < m; ++j)
             memcpy(out_host + (size_t)where[j] * h->dim, tmp.data() + j * (size_t)h->dim, (size_t)h->dim * 4);
+    }
+    return 0;
+}
+
+extern "C" int artmips_generation(artmips_t* h, uint64_t* out) {
+    if (!h || !out) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(h->gen_mutex);
+    *out = h->generation;
+    return 0;
+}
+
+extern "C" int artmips_download(artmips_t* h, uint64_t generation, int64_t row_offset, int64_t n_rows,
+                                void* host_rows, int32_t* host_ids) {
+    if (!h || !host_rows || !host_ids) return fail(ARTMIPS_ERR_ARG, "NULL argument");
+    if (n_rows < 0 || row_offset < 0) return fail(ARTMIPS_ERR_ARG, "negative range");
+    const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
+    const int64_t rows_per_buf = std::max<int64_t>(1, (16ll << 20) / (int64_t)row_bytes);
+    const size_t need = (size_t)rows_per_buf * (row_bytes + 4);
+    int64_t done = 0;
+    int which = 0;
+    while (done < n_rows) {
+        // one chunk per lock hold, so that a refresh that finishes meanwhile waits milliseconds, not
+        // for the whole download; the generation check makes a swapped index an error, not a mix
+        std::lock_guard<std::mutex> lock(h->gen_mutex);
+        if (h->generation != generation)
+            return fail(ARTMIPS_ERR_STATE, "the index was replaced while it was being downloaded");
+        if (row_offset + n_rows > h->n_rows)
+            return fail(ARTMIPS_ERR_ARG, "rows [%lld, %lld) outside the %lld rows of the index",
+                        (long long)row_offset, (long long)(row_offset + n_rows), (long long)h->n_rows);
+        const int64_t gpos = row_offset + done;
+        const int slot = (int)(gpos / h->chunk);
+        Shard& s = h->sh[slot];
+        const int64_t in_shard = gpos - s.live.row0;
+        const int64_t n = std::min<int64_t>(std::min<int64_t>(rows_per_buf, n_rows - done),
+                                            s.live.n_rows - in_shard);
+        DeviceGuard g(s.dev);
+        if (h->dl_pin_bytes < need) {
+            for (int i = 0; i < 2; ++i) {
+                if (h->dl_pin[i]) (void)hipHostFree(h->dl_pin[i]);
+                h->dl_pin[i] = nullptr;
+                HIP_TRY(hipHostMalloc(&h->dl_pin[i], need, hipHostMallocDefault));
+            }
+            h->dl_pin_bytes = need;
+        }
+        if (!h->dl_stream[slot]) HIP_TRY(hipStreamCreateWithFlags(&h->dl_stream[slot], hipStreamNonBlocking));
+        char* stage = (char*)h->dl_pin[which];
+        HIP_TRY(hipMemcpyAsync(stage, (const char*)s.live.rows + (size_t)in_shard * row_bytes,
+                               (size_t)n * row_bytes, hipMemcpyDeviceToHost, h->dl_stream[slot]));
+        HIP_TRY(hipMemcpyAsync(stage + (size_t)rows_per_buf * row_bytes, s.live.ids + in_shard, (size_t)n * 4,
+                               hipMemcpyDeviceToHost, h->dl_stream[slot]));
+        HIP_TRY(hipStreamSynchronize(h->dl_stream[slot]));
+        memcpy((char*)host_rows + (size_t)done * row_bytes, stage, (size_t)n * row_bytes);
+        memcpy(host_ids + done, stage + (size_t)rows_per_buf * row_bytes, (size_t)n * 4);
+        which ^= 1;
+        done += n;
     }
     return 0;
 }

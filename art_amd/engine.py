@@ -302,6 +302,26 @@ class MipsEngine(object):
                                      ctypes.c_void_p(out.ctypes.data)))
         return out
 
+    def generation(self):
+        """Counter that increases with every finalize(); pair with download()."""
+        out = ctypes.c_uint64(0)
+        check(lib.artmips_generation(self._h, ctypes.byref(out)))
+        return out.value
+
+    def download(self, row_offset, n_rows, generation=None):
+        """Rows [row_offset, row_offset + n_rows) of the live index and their passage ids, copied to
+        the host: (rows numpy [n, dim] in the storage dtype -- bfloat16 as raw uint16 -- , ids int32
+        [n]).  May be called from a second thread beside searches; fails if the index is replaced
+        (finalize) after `generation` was read."""
+        if generation is None:
+            generation = self.generation()
+        np_dt = {torch.float16: np.float16, torch.bfloat16: np.uint16, torch.float32: np.float32}[self.storage_dtype]
+        rows = np.empty((int(n_rows), self.dim), dtype=np_dt)
+        ids = np.empty((int(n_rows),), dtype=np.int32)
+        check(lib.artmips_download(self._h, ctypes.c_uint64(generation), int(row_offset), int(n_rows),
+                                   ctypes.c_void_p(rows.ctypes.data), ctypes.c_void_p(ids.ctypes.data)))
+        return rows, ids
+
     def grow_lists(self):
         check(lib.artmips_grow_lists(self._h))
 

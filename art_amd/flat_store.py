@@ -53,6 +53,63 @@ def write_flat(path, ids, rows, dtype_code=0):
     os.replace(tmp, path)
 
 
+def save_engine_flat(engine, path, chunk_rows=1 << 17):
+    """Write the live index of a MipsEngine as a flat store file, streaming it off the GPUs chunk by
+    chunk (artmips_download): the on-disk artefact after a device-side refresh, where the reference
+    has its merged pickle (indexer.py:156-163).  Safe to run on a background thread beside searches;
+    raises ArtmipsError if the index is replaced meanwhile.  Returns the number of rows written.
+
+    An index in id order (what the device refresh builds) is streamed straight through; any other
+    row order (an index built from a store's dict) is placed by id through a memory map."""
+    gen = engine.generation()
+    n = int(engine.n_rows)
+    dtype_code = {"torch.float16": 0, "torch.bfloat16": 1, "torch.float32": 2}[str(engine.storage_dtype)]
+    np_dt = _DT[dtype_code]
+    dim = engine.dim
+    # pass 1: the ids (4 bytes a row) decide where every row goes
+    ids = np.empty(n, dtype=np.int32)
+    sorted_already = True
+    prev = None
+    tmp = path + ".tmp"
+    rows_off = HEADER_BYTES + _ids_bytes(n)
+    with open(tmp, "wb") as f:
+        f.write(MAGIC + struct.pack("<IIQQ", 1, dtype_code, n, dim).ljust(HEADER_BYTES - len(MAGIC), b"\0"))
+        f.write(b"\0" * _ids_bytes(n))
+        for lo in range(0, n, chunk_rows):
+            cnt = min(chunk_rows, n - lo)
+            rows, cid = engine.download(lo, cnt, gen)
+            ids[lo:lo + cnt] = cid
+            if sorted_already:
+                if (prev is not None and cid[0] <= prev) or (cnt > 1 and np.any(np.diff(cid) <= 0)):
+                    sorted_already = False
+                prev = int(cid[-1])
+            f.write(rows.tobytes())  # in index order for now
+    if not sorted_already:
+        order = np.argsort(ids, kind="stable")
+        if np.any(np.diff(ids[order]) == 0):
+            os.remove(tmp)
+            raise ValueError("Unexpectedly tried to overwrite block data")  # duplicate id
+        rank = np.empty(n, dtype=np.int64)
+        rank[order] = np.arange(n, dtype=np.int64)
+        # pass 2: rows to their place in id order, chunk by chunk through a second file
+        tmp2 = path + ".tmp2"
+        src = np.memmap(tmp, dtype=np_dt, mode="r", offset=rows_off, shape=(n, dim))
+        with open(tmp2, "wb") as f:
+            f.write(MAGIC + struct.pack("<IIQQ", 1, dtype_code, n, dim).ljust(HEADER_BYTES - len(MAGIC), b"\0"))
+            f.write(ids[order].tobytes().ljust(_ids_bytes(n), b"\0"))
+            for lo in range(0, n, chunk_rows):
+                f.write(np.ascontiguousarray(src[order[lo:lo + chunk_rows]]).tobytes())
+        del src
+        os.remove(tmp)
+        os.replace(tmp2, path)
+    else:
+        with open(tmp, "r+b") as f:
+            f.seek(HEADER_BYTES)
+            f.write(ids.tobytes())
+        os.replace(tmp, path)
+    return n
+
+
 class FlatStore(object):
     """Memory-mapped view of a flat store file: .ids int32 [n], .rows [n, dim], .dtype_code."""
 
@@ -101,4 +158,4 @@ def flat_to_store(flat, embedding_path, rank=0):
     return st
 
 
-__all__ = ["write_flat", "FlatStore", "store_to_flat", "flat_to_store"]
+__all__ = ["write_flat", "FlatStore", "store_to_flat", "flat_to_store", "save_engine_flat"]

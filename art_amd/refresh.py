@@ -74,9 +74,13 @@ class DeviceIndexWriter(object):
         row_id, block_embeds = _as_cuda(row_id, block_embeds, self.device)
         self.engine.upload_scatter(block_embeds, row_id, self.id_base)
 
-    def commit(self):
+    def commit(self, save_flat=None, background=True):
         """Swap the new generation in.  Raises ValueError if a passage id was added twice and
-        ArtmipsError if some passage never arrived (the reference: art_index.py:59, indexer.py:161)."""
+        ArtmipsError if some passage never arrived (the reference: art_index.py:59, indexer.py:161).
+
+        save_flat: path of a flat store file to write from the new generation (the on-disk artefact
+        the reference's indexer leaves at --embedding-path, indexer.py:156-163); by default on a
+        background thread beside the training step's searches (returned as self.saver)."""
         _finalize(self.engine)
         idx = self.index
         idx.evidence_embeds = self.engine
@@ -87,6 +91,8 @@ class DeviceIndexWriter(object):
         from .art_index import _IdMap
 
         idx.id_map = _IdMap(idx.indices_arr)
+        self.saver = idx.save_flat(save_flat, background=background) if save_flat else None
+        return self.saver
 
 
 def route_by_owner(row_id, block_embeds, n_rows, id_base, world):

@@ -23,7 +23,8 @@
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
  *   - passage ids are int32 (the reference returns int32: art_index.py:297).
  *   - a handle is used by one thread at a time (the reference drives its index from one
- *     Python thread of one process per node: art_model.py:327,351); different handles are
+ *     Python thread of one process per node: art_model.py:327,351), with one exception:
+ *     artmips_download / artmips_generation may run on a second thread.  Different handles are
  *     independent, and the handle-less merges serialise per process on an internal lock.
  *   - top-k order: score descending, ties broken by LOWER passage id
  *     (BASELINE.json north_star); scores are fp32-accumulated dot products.
@@ -199,6 +200,22 @@ int artmips_grow_lists(artmips_t* h);
  * half of the sibling index's search (FaissMIPSIndex.search_mips_index,
  * art_index.py:190-193: faiss's search_and_reconstruct).  Synchronous. */
 int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_t n, float* out_host);
+
+/* Generation counter of the live index: it increases with every successful
+ * artmips_finalize.  Pair with artmips_download. */
+int artmips_generation(artmips_t* h, uint64_t* out);
+
+/* Copy rows [row_offset, row_offset + n_rows) of the live index (global row positions,
+ * across shards) and their passage ids to host memory, in the storage dtype.  This is the
+ * way back to the reference's on-disk artefact after a device-side refresh: the reference
+ * keeps its index "checkpoint" as the pickle at --embedding-path, rewritten on every refresh
+ * (indexer.py:156-163, art_index.py:72-100).  `generation` is the value artmips_generation
+ * returned when the export began: if a refresh replaces the index meanwhile the call fails with
+ * ARTMIPS_ERR_STATE instead of mixing two generations.  Uses its own streams and pinned
+ * staging and takes the handle's generation lock per 16 MiB chunk, so it MAY run on another
+ * thread beside searches and beside the upload calls of the next refresh. */
+int artmips_download(artmips_t* h, uint64_t generation, int64_t row_offset, int64_t n_rows,
+                     void* host_rows, int32_t* host_ids);
 
 /* Turn the HIP-event timing of the search pipeline on (default) or off.  The event records sit
  * between the kernels in the stream and cost a few microseconds each, which is noise on a 32 GB

@@ -138,3 +138,79 @@ def test_spmd_writer_two_ranks_one_gpu(tmp_path):
         s, i = np.load(tmp_path / ("s%d.npy" % r)), np.load(tmp_path / ("i%d.npy" % r))
         orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float16).astype(np.float64), ids, 30,
                        rel_tol=1e-3)
+
+
+@pytest.mark.parametrize("storage", [torch.float16, torch.bfloat16])
+def test_export_after_device_refresh_roundtrip(tmp_path, storage):
+    """The way back to disk after a device-side refresh (the reference's index checkpoint is the pickle
+    its indexer writes, indexer.py:156-163): commit(save_flat=...) streams the new generation into a
+    flat file on a background thread while searches go on; the file reloads into an identical index."""
+    from art_amd.art_index import DistributedBruteForceIndex
+    from art_amd.flat_store import FlatStore
+    from art_amd.refresh import DeviceIndexWriter
+    rows, queries = _data(n=6001)
+    n = rows.shape[0]
+    index = DistributedBruteForceIndex(768, None, devices=[0, 0, 0], storage_dtype=storage)
+    index.score_dtype = torch.float32
+    w = DeviceIndexWriter(index, n, id_base=1)
+    perm = np.random.Generator(np.random.PCG64(3)).permutation(n)
+    d_rows = torch.from_numpy(rows).cuda()
+    for b in range(0, n, 500):
+        sel = torch.from_numpy(perm[b:b + 500]).cuda()
+        w.add_block_data(sel + 1, d_rows[sel])
+    path = str(tmp_path / "evidence.flat")
+    saver = w.commit(save_flat=path)          # background thread
+    q = torch.from_numpy(queries).cuda().to(storage)
+    s0, i0 = index.search_mips_index(q, 25)   # searches run beside the export
+    saver.join(60)
+    assert not saver.is_alive() and saver.error is None and saver.rows_written == n
+    flat = FlatStore(path)
+    assert flat.n_rows == n and flat.dim == 768 and np.array_equal(flat.ids, np.arange(1, n + 1))
+    want = torch.from_numpy(rows).to(storage)
+    got = torch.from_numpy(np.asarray(flat.rows))
+    got = got.view(torch.bfloat16) if storage == torch.bfloat16 else got
+    assert torch.equal(got, want)
+    again = DistributedBruteForceIndex(768, None, devices=[0], storage_dtype=storage)
+    again.score_dtype = torch.float32
+    again.add_flat_store(flat)
+    s1, i1 = again.search_mips_index(q, 25)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+
+
+def test_export_unsorted_index_and_generation_guard(tmp_path):
+    """An index built from a store keeps the dict's insertion order (art_index.py:244); its export is
+    placed by id.  to_store() gives the reference-format dict back.  A download that started before a
+    refresh fails instead of mixing two generations."""
+    from art_amd._lib import ArtmipsError
+    from art_amd.art_index import DistributedBruteForceIndex, OpenRetreivalDataStore
+    from art_amd.flat_store import FlatStore
+    rows, queries = _data(n=3000, seed=9)
+    n = rows.shape[0]
+    ids = np.random.Generator(np.random.PCG64(5)).permutation(n).astype(np.int64) + 1
+    store = OpenRetreivalDataStore(str(tmp_path / "e.pkl"), load_from_path=False, rank=0)
+    store.add_block_data(ids, rows)
+    index = DistributedBruteForceIndex(768, store, devices=[0, 0])
+    assert index.save_flat(str(tmp_path / "u.flat")) == n
+    flat = FlatStore(str(tmp_path / "u.flat"))
+    assert np.array_equal(flat.ids, np.arange(1, n + 1))
+    order = np.argsort(ids)
+    assert np.array_equal(np.asarray(flat.rows), rows.astype(np.float16)[order])
+    # the reference-format store, in the index's row order, bit for bit
+    back = index.to_store()
+    assert list(back.embed_data.keys()) == list(ids) and isinstance(next(iter(back.embed_data)), np.int64)
+    first = back.embed_data[ids[0]]
+    assert first.dtype == np.float16 and np.array_equal(first, rows[0].astype(np.float16))
+    assert back.embedding_path == str(tmp_path / "e.pkl")
+    # generation guard
+    eng = index.evidence_embeds
+    gen = eng.generation()
+    r, i = eng.download(10, 5, gen)
+    assert np.array_equal(i, ids[10:15].astype(np.int32)) and np.array_equal(r, rows[10:15].astype(np.float16))
+    eng.begin(n)
+    eng.upload_host(rows.astype(np.float16), ids.astype(np.int32))
+    eng.finalize()
+    assert eng.generation() == gen + 1
+    with pytest.raises(ArtmipsError):
+        eng.download(10, 5, gen)
+    with pytest.raises(ArtmipsError):
+        eng.download(n - 2, 5)  # beyond the last row
