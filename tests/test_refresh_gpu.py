@@ -167,7 +167,7 @@ def test_export_after_device_refresh_roundtrip(tmp_path, storage):
     flat = FlatStore(path)
     assert flat.n_rows == n and flat.dim == 768 and np.array_equal(flat.ids, np.arange(1, n + 1))
     want = torch.from_numpy(rows).to(storage)
-    got = torch.from_numpy(np.asarray(flat.rows))
+    got = torch.from_numpy(np.array(flat.rows))
     got = got.view(torch.bfloat16) if storage == torch.bfloat16 else got
     assert torch.equal(got, want)
     again = DistributedBruteForceIndex(768, None, devices=[0], storage_dtype=storage)

@@ -466,3 +466,27 @@ def test_large_k_integer_ties_bit_exact(gu, span, k, route):
     np.testing.assert_array_equal(i, ei)
     np.testing.assert_array_equal(s, es.astype(np.float32))
     eng.close()
+
+
+def test_search_on_a_side_stream(gu):
+    """The boundary hands torch's CURRENT stream to the library: a search issued inside
+    torch.cuda.stream(side) must order itself after the work that produced its queries on that stream
+    and leave results that later work on that stream can use, with the default stream idle or busy."""
+    from art_amd.distributed import SpmdSearcher
+    rows, queries, ids = _random_case(40000, 64, 768, seed=51)
+    eng = gu.build_engine(rows, ids)
+    q_host = torch.from_numpy(queries)
+    want_s, want_i = eng.search(q_host.cuda(), 32, score_dtype=torch.float32)
+    side = torch.cuda.Stream()
+    busy = torch.empty((8192, 8192), device="cuda")
+    with torch.cuda.stream(side):
+        # queries produced on the side stream right before the call (an encoder's output)
+        q = (q_host.cuda(non_blocking=True).float() * 2.0 * 0.5).half()
+        busy.normal_()  # keep the side stream occupied in front of the search
+        s, i = eng.search(q, 32, score_dtype=torch.float32)
+        total = (s.sum() + i.sum()).item()  # consumed on the same stream
+        s2, i2 = SpmdSearcher(eng).search(q, 32, score_dtype=torch.float32)
+    side.synchronize()
+    assert torch.equal(i, want_i) and torch.equal(s, want_s) and np.isfinite(total)
+    assert torch.equal(i2, want_i) and torch.equal(s2, want_s)
+    eng.close()
