@@ -99,8 +99,20 @@ def cpu_baseline(n_rows, q, k):
     }
 
 
+def private_stdout():
+    """stdout must carry exactly ONE JSON line, but native libraries write to file descriptor 1 too
+    (RCCL prints a five-line version banner there when NCCL_DEBUG=VERSION, which the GPU boxes set).
+    Keep a private copy of the real stdout for the JSON line and point fd 1 at stderr for everything
+    else, so that the banner stays in the logs."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
+    json_out = private_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -242,7 +254,7 @@ def main():
         }
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     engine.close()
     if spmd:
         dist.destroy_process_group()

@@ -27,25 +27,24 @@ k = 32
 words = MipsEngine.packed_words(64, k)
 local = torch.empty(words, dtype=torch.int32, device="cuda")
 gathered = torch.empty((1, words), dtype=torch.int32, device="cuda")
-flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-names = ["search_local_async", "all_gather_into_tensor", "merge_packed", "flag.item()", "engine.info()"]
+names = ["search_local_async", "all_gather_into_tensor", "merge_packed_sync (merge + the step's wait)"]
 acc = [0.0] * len(names)
 N = 300
+eng.set_stats(False)  # as bench.py runs three steps out of four
 for it in range(N + 20):
     t = [time.perf_counter()]
     eng.search_local_async(0, q, k, local)
     t.append(time.perf_counter())
     dist.all_gather_into_tensor(gathered, local)
     t.append(time.perf_counter())
-    out = MipsEngine.merge_packed(gathered, 64, k, torch.float16, flag)
-    t.append(time.perf_counter())
-    f = int(flag.item())
-    t.append(time.perf_counter())
-    eng.info()
+    out = MipsEngine.merge_packed_sync(gathered, 64, k, torch.float16)
     t.append(time.perf_counter())
     if it >= 20:
         for i in range(len(names)):
             acc[i] += t[i + 1] - t[i]
+eng.set_stats(True)
+eng.search_local_async(0, q, k, local)
+torch.cuda.synchronize()
 tot = sum(acc) / N * 1e6
 print("rows %d: step %.1f us on the host" % (rows, tot))
 for n, a in zip(names, acc):
