@@ -17,7 +17,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tests", "golden", "fx_tokens")
 REF = "/root/reference/megatron/data/indexed_dataset.py"
 

@@ -50,3 +50,14 @@ def test_no_oracle_or_cpu_fallback_in_product():
             code = re.sub(r'""".*?"""', "", src, flags=re.S)
             code = re.sub(r"#.*", "", code)
             assert "torch.topk(" not in code and "torch.matmul(" not in code, fn
+
+
+def test_only_tests_smoke_and_bench_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under art_amd/ or tools/ may import it (the fixture
+    generator and the stress runner live under tests/ for that reason)."""
+    for top in ("art_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h", ".sh")):
+                    src = open(os.path.join(dirpath, fn)).read()
+                    assert "import oracle" not in src and "from oracle" not in src, os.path.join(dirpath, fn)

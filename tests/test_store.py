@@ -1,5 +1,5 @@
 """CPU tests of the evidence store mirror (art_amd.art_index.OpenRetreivalDataStore) against the
-fixture produced by the REFERENCE'S OWN class (tools/make_golden.py: art_index.py:16-100 imported by
+fixture produced by the REFERENCE'S OWN class (tests/golden/make_golden.py: art_index.py:16-100 imported by
 path): pickle layout, key and value types, float16 cast, merge order, duplicate-id error."""
 import json
 import os

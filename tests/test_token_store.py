@@ -1,6 +1,6 @@
 """CPU tests of the token datasets: the reader and writer against files the
 REFERENCE'S OWN MMapIndexedDatasetBuilder wrote and its reader read back (tests/golden/fx_tokens,
-tools/make_golden_tokens.py), the vectorised host fetch against the structure of
+tests/golden/make_golden_tokens.py), the vectorised host fetch against the structure of
 art_model.py:367-381, and the C ABI of libarttok.so (load + symbols, no compute without a GPU)."""
 import ctypes
 import json
