@@ -1108,6 +1108,7 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
     // replicate the queries, search every shard on its own stream, bring the (score, id) lists
     // to slot 0 and merge there.  Only Q*k*8 bytes per shard move between devices.
     Shard& s0 = h->sh[0];
+    const auto t_entry = std::chrono::steady_clock::now();
     const size_t q_bytes = (size_t)n_q * h->dim * elem_size(q_dtype);
     const size_t list_elems = (size_t)n_q * k;
     {
@@ -1139,6 +1140,8 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
                                   (int32_t*)s.loc_ids.p, s.stream, i == used[0]});
         if ((rc = shard_enqueue(h, calls.back()))) return rc;
     }
+    const double enqueue_all_us =
+        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
     for (ShardCall& c : calls) {
         Shard& s = h->sh[c.slot];
         bool overflow = false;
@@ -1167,6 +1170,7 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
     if (rc) return rc;
     DeviceGuard g(s0.dev);
     HIP_TRY(hipStreamSynchronize(st));  // the search entry points return with the stream drained
+    h->host_enqueue_us = enqueue_all_us;  // entry .. last shard's pipeline enqueued (all shards)
     return 0;
 }
 

@@ -77,7 +77,7 @@ typedef struct artmips_info {
     int32_t last_scan_launches;
     int32_t last_retries; /* candidate-list overflow retries taken by the last call      */
     int64_t last_candidates; /* candidates kept by the filter, summed over queries        */
-    float last_host_enqueue_us; /* host time to plan + enqueue the last search (slot 0)     */
+    float last_host_enqueue_us; /* host time to plan + enqueue the last search (all shards) */
     float last_host_sync_us;    /* host time spent waiting for the stream afterwards        */
 } artmips_info_t;
 
