@@ -14,8 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 #include <unistd.h>
 
@@ -82,6 +86,64 @@ struct Shard {
     int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints)
 };
 
+// One persistent helper thread per extra shard of a one-process / many-shards handle: the host needs
+// ~19 us to plan and enqueue one shard's pipeline (peer copy of the queries, four launches, status
+// copy), so a single thread would start the eighth GPU ~135 us after the first (a fifth of a 0.65 ms
+// step).  The workers only enqueue; the calling thread collects.
+struct ShardWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, stop = false;
+    int rc = 0;
+    char err[512] = "";
+
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop) return;
+            std::function<int()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            const int r = j();
+            lk.lock();
+            rc = r;
+            if (r) {
+                strncpy(err, g_err, sizeof(err) - 1);
+                err[sizeof(err) - 1] = 0;
+            }
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            has_job = true;
+            done = false;
+        }
+        cv.notify_all();
+    }
+    // returns the job's status; on failure the worker's message becomes the caller's last error
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        done = false;
+        return rc ? fail(rc, "%s", err) : 0;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct artmips {
     int n_dev = 0;
     int dim = 0;
@@ -94,6 +156,7 @@ struct artmips {
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
+    std::vector<std::unique_ptr<ShardWorker>> workers;  // [n_dev], slot 0 unused; created on first use
     // artmips_download: its own pinned staging and streams, so that it can run beside searches; the
     // mutex orders it against the generation swap of artmips_finalize / artmips_destroy
     std::mutex gen_mutex;
@@ -304,6 +367,9 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
 
 extern "C" void artmips_destroy(artmips_t* h) {
     if (!h) return;
+    for (auto& w : h->workers)
+        if (w) w->shutdown();
+    h->workers.clear();
     for (int i = 0; i < h->n_dev; ++i) {
         Shard& s = h->sh[i];
         DeviceGuard g(s.dev);
@@ -1119,26 +1185,56 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
     }
     int li = 0;
     std::vector<int> used;
-    for (int i = 0; i < h->n_dev; ++i) {
-        Shard& s = h->sh[i];
-        if (s.live.n_rows == 0) continue;
-        DeviceGuard g(s.dev);
-        if ((rc = ensure(s.qin, q_bytes))) return rc;
-        if ((rc = ensure(s.loc_scores, list_elems * 4))) return rc;
-        if ((rc = ensure(s.loc_ids, list_elems * 4))) return rc;
-        HIP_TRY(hipStreamWaitEvent(s.stream, s0.ev_ready, 0));
-        HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
-        used.push_back(i);
-    }
-    // enqueue every shard's pipeline on its own stream first, so that the devices work at the same
+    for (int i = 0; i < h->n_dev; ++i)
+        if (h->sh[i].live.n_rows > 0) used.push_back(i);
+    // Enqueue every shard's pipeline on its own stream first, so that the devices work at the same
     // time; then collect them one by one.  A shard whose candidate lists overflowed is searched
     // again on its own (larger lists) before its result is shipped.
-    std::vector<ShardCall> calls;
-    for (int i : used) {
-        Shard& s = h->sh[i];
-        calls.push_back(ShardCall{i, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
-                                  (int32_t*)s.loc_ids.p, s.stream, i == used[0]});
-        if ((rc = shard_enqueue(h, calls.back()))) return rc;
+    // Each shard's enqueue (scratch, wait for the queries' producer, peer copy of the queries, the
+    // pipeline) is one job: the first shard's runs here, the others on their worker threads
+    // (ARTMIPS_ENQUEUE_THREADS=0: all of them here, one after the other).
+    std::vector<ShardCall> calls(used.size());
+    auto enqueue_one = [h, q_dev, q_dtype, n_q, k, q_bytes, list_elems, &s0, &calls](size_t u, int slot,
+                                                                                    bool stats) -> int {
+        Shard& s = h->sh[slot];
+        DeviceGuard g(s.dev);
+        int r = 0;
+        if ((r = ensure(s.qin, q_bytes))) return r;
+        if ((r = ensure(s.loc_scores, list_elems * 4))) return r;
+        if ((r = ensure(s.loc_ids, list_elems * 4))) return r;
+        HIP_TRY(hipStreamWaitEvent(s.stream, s0.ev_ready, 0));
+        HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
+        calls[u] = ShardCall{slot, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
+                             (int32_t*)s.loc_ids.p, s.stream, stats};
+        return shard_enqueue(h, calls[u]);
+    };
+    bool threaded = used.size() > 1;
+    if (const char* e = getenv("ARTMIPS_ENQUEUE_THREADS")) threaded = threaded && atoi(e) != 0;
+    if (threaded) {
+        if (h->workers.size() != (size_t)h->n_dev) h->workers.resize(h->n_dev);
+        for (size_t u = 1; u < used.size(); ++u) {
+            std::unique_ptr<ShardWorker>& w = h->workers[used[u]];
+            if (!w) {
+                w.reset(new ShardWorker());
+                ShardWorker* raw = w.get();
+                raw->th = std::thread([raw] { raw->loop(); });
+            }
+            const int slot = used[u];
+            w->post([enqueue_one, u, slot] { return enqueue_one(u, slot, false); });
+        }
+        rc = enqueue_one(0, used[0], true);
+        for (size_t u = 1; u < used.size(); ++u) {  // wait for every worker, even after a failure
+            const int r = h->workers[used[u]]->wait();
+            if (r && !rc) rc = r;
+        }
+        if (rc) {
+            // do not return with pipelines still running on buffers the caller may free
+            for (int i : used) { DeviceGuard g(h->sh[i].dev); (void)hipStreamSynchronize(h->sh[i].stream); }
+            return rc;
+        }
+    } else {
+        for (size_t u = 0; u < used.size(); ++u)
+            if ((rc = enqueue_one(u, used[u], u == 0))) return rc;
     }
     const double enqueue_all_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
