@@ -110,6 +110,55 @@ def save_engine_flat(engine, path, chunk_rows=1 << 17):
     return n
 
 
+def save_engine_flat_shared(engine, path, row0, n_total, rank, barrier, chunk_rows=1 << 17):
+    """One flat store file written by several processes, each holding the rows [row0, row0 + its
+    engine's rows) of an index that is in global id order (what the SPMD device refresh builds:
+    art_amd.refresh.SpmdIndexWriter).  Collective: every rank calls it with the same path and
+    n_total; `barrier` is a callable that returns once every rank has reached it
+    (torch.distributed.barrier).  Rank 0 lays the file out, every rank streams its shard off its GPU
+    into its slice through a memory map, rank 0 checks that the ids ascend and puts the file in place.
+    The ranks must see one filesystem (they are the GPUs of one node).  Returns n_total."""
+    dtype_code = {"torch.float16": 0, "torch.bfloat16": 1, "torch.float32": 2}[str(engine.storage_dtype)]
+    np_dt = _DT[dtype_code]
+    dim = engine.dim
+    n_local = int(engine.n_rows)
+    tmp = path + ".tmp"
+    rows_off = HEADER_BYTES + _ids_bytes(n_total)
+    total_bytes = rows_off + n_total * dim * np.dtype(np_dt).itemsize
+    if rank == 0:
+        with open(tmp, "wb") as f:
+            f.write(MAGIC + struct.pack("<IIQQ", 1, dtype_code, n_total, dim).ljust(HEADER_BYTES - len(MAGIC), b"\0"))
+            f.truncate(total_bytes)
+    barrier()
+    gen = engine.generation()
+    ids_mm = np.memmap(tmp, dtype=np.int32, mode="r+", offset=HEADER_BYTES, shape=(n_total,))
+    rows_mm = np.memmap(tmp, dtype=np_dt, mode="r+", offset=rows_off, shape=(n_total, dim))
+    for lo in range(0, n_local, chunk_rows):
+        cnt = min(chunk_rows, n_local - lo)
+        rows, ids = engine.download(lo, cnt, gen)
+        rows_mm[row0 + lo:row0 + lo + cnt] = rows
+        ids_mm[row0 + lo:row0 + lo + cnt] = ids
+    rows_mm.flush()
+    ids_mm.flush()
+    del rows_mm, ids_mm
+    barrier()
+    err = None
+    if rank == 0:
+        all_ids = np.memmap(tmp, dtype=np.int32, mode="r", offset=HEADER_BYTES, shape=(n_total,))
+        if n_total > 1 and not bool(np.all(np.diff(all_ids) > 0)):
+            err = ValueError("the shards are not in ascending id order: a shared flat file needs the "
+                             "index the device refresh builds")
+        del all_ids
+        if err is None:
+            os.replace(tmp, path)
+        else:
+            os.remove(tmp)
+    barrier()
+    if err is not None:
+        raise err
+    return n_total
+
+
 class FlatStore(object):
     """Memory-mapped view of a flat store file: .ids int32 [n], .rows [n, dim], .dtype_code."""
 
@@ -158,4 +207,4 @@ def flat_to_store(flat, embedding_path, rank=0):
     return st
 
 
-__all__ = ["write_flat", "FlatStore", "store_to_flat", "flat_to_store", "save_engine_flat"]
+__all__ = ["write_flat", "FlatStore", "store_to_flat", "flat_to_store", "save_engine_flat", "save_engine_flat_shared"]

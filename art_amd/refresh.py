@@ -143,7 +143,10 @@ class SpmdIndexWriter(object):
         self._ids.append(row_id.reshape(-1).to(torch.int64))
         self._rows.append(block_embeds)
 
-    def commit(self):
+    def commit(self, save_flat=None):
+        """Collective.  save_flat: path of ONE flat store file that every rank writes its shard into
+        (flat_store.save_engine_flat_shared) once the new generation is live: the on-disk artefact the
+        reference's indexer leaves at --embedding-path (indexer.py:156-163)."""
         dim = self.engine.dim if self.engine is not None else (self._rows[0].shape[1] if self._rows else 0)
         if self._ids:
             ids = torch.cat(self._ids)
@@ -171,6 +174,11 @@ class SpmdIndexWriter(object):
             self._sink(rows, ids, self.id_base + self.lo)
         if self.engine is not None:
             _finalize(self.engine)
+            if save_flat:
+                from .flat_store import save_engine_flat_shared
+
+                barrier = (lambda: dist.barrier(group=self.group)) if self.world > 1 else (lambda: None)
+                save_engine_flat_shared(self.engine, save_flat, self.lo, self.n_rows, self.rank, barrier)
         return int(ids.numel())
 
 

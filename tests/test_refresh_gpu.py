@@ -119,7 +119,7 @@ def _spmd_worker(rank, world, port, out_dir):
         for b in range(0, len(mine), 128):
             sel = mine[b:b + 128]
             w.add_block_data(torch.from_numpy(sel + 1).cuda(), torch.from_numpy(rows[sel]).cuda())
-        w.commit()
+        w.commit(save_flat=os.path.join(out_dir, "spmd.flat"))  # every rank writes its shard's slice
         s, i = engine_spmd_search(eng, torch.from_numpy(queries).cuda(), 30, score_dtype=torch.float32)
         torch.cuda.synchronize()
         np.save(os.path.join(out_dir, "s%d.npy" % rank), s.cpu().numpy())
@@ -138,6 +138,12 @@ def test_spmd_writer_two_ranks_one_gpu(tmp_path):
         s, i = np.load(tmp_path / ("s%d.npy" % r)), np.load(tmp_path / ("i%d.npy" % r))
         orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float16).astype(np.float64), ids, 30,
                        rel_tol=1e-3)
+    # the one flat file the two ranks wrote together holds the whole index in id order
+    from art_amd.flat_store import FlatStore
+    flat = FlatStore(str(tmp_path / "spmd.flat"))
+    assert flat.n_rows == 4001 and np.array_equal(flat.ids, ids.astype(np.int32))
+    assert np.array_equal(np.array(flat.rows), rows.astype(np.float16))
+    assert not os.path.exists(str(tmp_path / "spmd.flat.tmp"))
 
 
 @pytest.mark.parametrize("storage", [torch.float16, torch.bfloat16])
