@@ -5,6 +5,7 @@ stream); all search work happens in the HIP library behind the C ABI.  The
 reference-shaped classes in ``art_amd.art_index`` are built on top of this.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -68,12 +69,19 @@ class MipsEngine(object):
         check(lib.artmips_create(arr, len(self.devices), self.dim, _abi_dtype(storage_dtype),
                                  ctypes.byref(self._h)))
         self.n_rows = 0
+        # close() must not destroy the handle under a download chunk running on another thread
+        # (index.save_flat(background=True)); later chunks of that export find the engine closed
+        self._dl_lock = threading.Lock()
 
     # ---- lifetime ---------------------------------------------------------------------------
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib.artmips_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        lock = getattr(self, "_dl_lock", None)
+        if lock is None:  # constructor failed before the handle existed
+            return
+        with lock:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                lib.artmips_destroy(self._h)
+                self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -305,7 +313,10 @@ class MipsEngine(object):
     def generation(self):
         """Counter that increases with every finalize(); pair with download()."""
         out = ctypes.c_uint64(0)
-        check(lib.artmips_generation(self._h, ctypes.byref(out)))
+        with self._dl_lock:
+            if not self._h.value:
+                raise ArtmipsError(-3, "the engine is closed")
+            check(lib.artmips_generation(self._h, ctypes.byref(out)))
         return out.value
 
     def download(self, row_offset, n_rows, generation=None):
@@ -318,8 +329,11 @@ class MipsEngine(object):
         np_dt = {torch.float16: np.float16, torch.bfloat16: np.uint16, torch.float32: np.float32}[self.storage_dtype]
         rows = np.empty((int(n_rows), self.dim), dtype=np_dt)
         ids = np.empty((int(n_rows),), dtype=np.int32)
-        check(lib.artmips_download(self._h, ctypes.c_uint64(generation), int(row_offset), int(n_rows),
-                                   ctypes.c_void_p(rows.ctypes.data), ctypes.c_void_p(ids.ctypes.data)))
+        with self._dl_lock:
+            if not self._h.value:
+                raise ArtmipsError(-3, "the engine was closed while its index was being downloaded")
+            check(lib.artmips_download(self._h, ctypes.c_uint64(generation), int(row_offset), int(n_rows),
+                                       ctypes.c_void_p(rows.ctypes.data), ctypes.c_void_p(ids.ctypes.data)))
         return rows, ids
 
     def grow_lists(self):

@@ -220,3 +220,32 @@ def test_export_unsorted_index_and_generation_guard(tmp_path):
         eng.download(10, 5, gen)
     with pytest.raises(ArtmipsError):
         eng.download(n - 2, 5)  # beyond the last row
+
+
+def test_close_during_background_export_is_safe(tmp_path):
+    """update_index() / close() right after save_flat(background=True): the handle is not destroyed
+    under a running download chunk, and the export ends with an error instead of a crash."""
+    from art_amd.art_index import DistributedBruteForceIndex
+    from art_amd.refresh import DeviceIndexWriter
+    rows, _ = _data(n=20000)
+    index = DistributedBruteForceIndex(768, None, devices=[0])
+    w = DeviceIndexWriter(index, rows.shape[0], id_base=1)
+    w.add_block_data(torch.arange(1, rows.shape[0] + 1).cuda(), torch.from_numpy(rows).cuda())
+    w.commit()
+    import art_amd.flat_store as fs
+    saver = None
+    orig = fs.save_engine_flat
+
+    def slow_save(engine, path, chunk_rows=256):  # many small chunks, so that close() lands between two
+        return orig(engine, path, chunk_rows)
+
+    fs.save_engine_flat = slow_save
+    try:
+        saver = index.save_flat(str(tmp_path / "x.flat"), background=True)
+        index._free()  # what update_index() / reset_index() do first
+        saver.join(60)
+    finally:
+        fs.save_engine_flat = orig
+    assert not saver.is_alive()
+    # either the export had finished already, or it stopped with the "closed" error; never a crash
+    assert saver.error is None or "closed" in str(saver.error)
