@@ -163,7 +163,7 @@ struct artmips {
     uint64_t generation = 0;
     void* dl_pin[2] = {nullptr, nullptr};
     size_t dl_pin_bytes = 0;
-    hipStream_t dl_stream[ARTMIPS_MAX_DEVICES] = {};
+    hipStream_t dl_stream[ARTMIPS_MAX_DEVICES][2] = {};
     // gather buffers on slot 0 for the multi-shard merge
     DevBuf g_scores, g_ids, m_keys, m_status;
     // stats
@@ -400,9 +400,9 @@ extern "C" void artmips_destroy(artmips_t* h) {
         }
     }
     for (int i = 0; i < h->n_dev; ++i) {
-        if (!h->dl_stream[i]) continue;
         DeviceGuard g(h->sh[i].dev);
-        (void)hipStreamDestroy(h->dl_stream[i]);
+        for (int b = 0; b < 2; ++b)
+            if (h->dl_stream[i][b]) (void)hipStreamDestroy(h->dl_stream[i][b]);
     }
     delete h;
 }
@@ -1338,45 +1338,79 @@ extern "C" int artmips_download(artmips_t* h, uint64_t generation, int64_t row_o
     const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
     const int64_t rows_per_buf = std::max<int64_t>(1, (16ll << 20) / (int64_t)row_bytes);
     const size_t need = (size_t)rows_per_buf * (row_bytes + 4);
+    // Two pinned buffers, two streams per shard: while chunk i travels device -> pinned buffer, chunk
+    // i-1 is copied from the other pinned buffer to its place in the caller's memory.
+    struct Pending {
+        bool on = false;
+        int slot = 0, buf = 0;
+        int64_t at = 0, n = 0;
+    } prev;
+    auto drain = [&](const Pending& p) -> int {
+        DeviceGuard g(h->sh[p.slot].dev);
+        HIP_TRY(hipStreamSynchronize(h->dl_stream[p.slot][p.buf]));
+        const char* stage = (const char*)h->dl_pin[p.buf];
+        memcpy((char*)host_rows + (size_t)p.at * row_bytes, stage, (size_t)p.n * row_bytes);
+        memcpy(host_ids + p.at, stage + (size_t)rows_per_buf * row_bytes, (size_t)p.n * 4);
+        return 0;
+    };
     int64_t done = 0;
     int which = 0;
+    int rc = 0;
     while (done < n_rows) {
-        // one chunk per lock hold, so that a refresh that finishes meanwhile waits milliseconds, not
-        // for the whole download; the generation check makes a swapped index an error, not a mix
-        std::lock_guard<std::mutex> lock(h->gen_mutex);
-        if (h->generation != generation)
-            return fail(ARTMIPS_ERR_STATE, "the index was replaced while it was being downloaded");
-        if (row_offset + n_rows > h->n_rows)
-            return fail(ARTMIPS_ERR_ARG, "rows [%lld, %lld) outside the %lld rows of the index",
-                        (long long)row_offset, (long long)(row_offset + n_rows), (long long)h->n_rows);
-        const int64_t gpos = row_offset + done;
-        const int slot = (int)(gpos / h->chunk);
-        Shard& s = h->sh[slot];
-        const int64_t in_shard = gpos - s.live.row0;
-        const int64_t n = std::min<int64_t>(std::min<int64_t>(rows_per_buf, n_rows - done),
-                                            s.live.n_rows - in_shard);
-        DeviceGuard g(s.dev);
-        if (h->dl_pin_bytes < need) {
-            for (int i = 0; i < 2; ++i) {
-                if (h->dl_pin[i]) (void)hipHostFree(h->dl_pin[i]);
-                h->dl_pin[i] = nullptr;
-                HIP_TRY(hipHostMalloc(&h->dl_pin[i], need, hipHostMallocDefault));
+        Pending cur;
+        {
+            // one chunk is issued per lock hold, so that a refresh that finishes meanwhile waits
+            // microseconds; the generation check makes a swapped index an error, not a mix.  A chunk
+            // in flight when the lock is released is safe: artmips_finalize synchronises the device
+            // before it frees the old generation.
+            std::lock_guard<std::mutex> lock(h->gen_mutex);
+            if (h->generation != generation) {
+                rc = fail(ARTMIPS_ERR_STATE, "the index was replaced while it was being downloaded");
+                break;
             }
-            h->dl_pin_bytes = need;
+            if (row_offset + n_rows > h->n_rows) {
+                rc = fail(ARTMIPS_ERR_ARG, "rows [%lld, %lld) outside the %lld rows of the index",
+                          (long long)row_offset, (long long)(row_offset + n_rows), (long long)h->n_rows);
+                break;
+            }
+            const int64_t gpos = row_offset + done;
+            const int slot = (int)(gpos / h->chunk);
+            Shard& s = h->sh[slot];
+            const int64_t in_shard = gpos - s.live.row0;
+            const int64_t n = std::min<int64_t>(std::min<int64_t>(rows_per_buf, n_rows - done),
+                                                s.live.n_rows - in_shard);
+            DeviceGuard g(s.dev);
+            if (h->dl_pin_bytes < need) {
+                for (int i = 0; i < 2; ++i) {
+                    if (h->dl_pin[i]) (void)hipHostFree(h->dl_pin[i]);
+                    h->dl_pin[i] = nullptr;
+                    HIP_TRY(hipHostMalloc(&h->dl_pin[i], need, hipHostMallocDefault));
+                }
+                h->dl_pin_bytes = need;
+            }
+            hipStream_t& st = h->dl_stream[slot][which];
+            if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            char* stage = (char*)h->dl_pin[which];
+            HIP_TRY(hipMemcpyAsync(stage, (const char*)s.live.rows + (size_t)in_shard * row_bytes,
+                                   (size_t)n * row_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(stage + (size_t)rows_per_buf * row_bytes, s.live.ids + in_shard,
+                                   (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            cur.on = true;
+            cur.slot = slot;
+            cur.buf = which;
+            cur.at = done;
+            cur.n = n;
         }
-        if (!h->dl_stream[slot]) HIP_TRY(hipStreamCreateWithFlags(&h->dl_stream[slot], hipStreamNonBlocking));
-        char* stage = (char*)h->dl_pin[which];
-        HIP_TRY(hipMemcpyAsync(stage, (const char*)s.live.rows + (size_t)in_shard * row_bytes,
-                               (size_t)n * row_bytes, hipMemcpyDeviceToHost, h->dl_stream[slot]));
-        HIP_TRY(hipMemcpyAsync(stage + (size_t)rows_per_buf * row_bytes, s.live.ids + in_shard, (size_t)n * 4,
-                               hipMemcpyDeviceToHost, h->dl_stream[slot]));
-        HIP_TRY(hipStreamSynchronize(h->dl_stream[slot]));
-        memcpy((char*)host_rows + (size_t)done * row_bytes, stage, (size_t)n * row_bytes);
-        memcpy(host_ids + done, stage + (size_t)rows_per_buf * row_bytes, (size_t)n * 4);
+        if (prev.on && (rc = drain(prev))) { prev = cur; break; }
+        prev = cur;
         which ^= 1;
-        done += n;
+        done += cur.n;
     }
-    return 0;
+    if (prev.on) {
+        const int r = drain(prev);   // also on the error paths: nothing may stay in flight into pinned memory
+        if (r && !rc) rc = r;
+    }
+    return rc;
 }
 
 extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
