@@ -182,7 +182,8 @@ int artmips_merge_packed(int device, const int32_t* packed, int n_lists, int64_t
                          void* out_scores, int score_dtype, int32_t* out_ids, int32_t* out_flag,
                          void* stream);
 
-/* artmips_merge_packed followed by the step's one host wait: the merge writes the OR of
+/* artmips_merge_packed followed by the step's one host wait (where the reference's caller
+ * waits in its two broadcasts and .tolist(), art_model.py:361-365, evaluate.py:173-185): the merge writes the OR of
  * the lists' status words straight into a pinned host word (no device-to-host copy is
  * queued), `stream` is synchronised and the word is returned in *flag_host_out (a HOST
  * pointer).  On return the merged lists are complete.  Calls on one device are serialised. */
@@ -202,7 +203,9 @@ int artmips_grow_lists(artmips_t* h);
 int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_t n, float* out_host);
 
 /* Generation counter of the live index: it increases with every successful
- * artmips_finalize.  Pair with artmips_download. */
+ * artmips_finalize, i.e. with every refresh (update_evidence_embedding, art_model.py:336-342).
+ * Pair with artmips_download.  No counterpart in the reference, whose index is rebuilt
+ * in place. */
 int artmips_generation(artmips_t* h, uint64_t* out);
 
 /* Copy rows [row_offset, row_offset + n_rows) of the live index (global row positions,
