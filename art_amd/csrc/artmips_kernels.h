@@ -391,12 +391,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
         thr[j] = (MODE == MODE_FILTER) ? (a.ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
-    // drain these loads before any LDS-DMA is in flight, so that hipcc never has a reason to put a
-    // vmcnt(0) inside the streaming loop (the asm loads into AGPRs are not counted by hipcc at all)
-    wait_vmcnt<0>();
-    settle_queries<NQ, KSTEPS, VB, ASM_PATH, 0>(bq);
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
+    // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image
     // MFMA side: lane (r,g), k-step s reads byte r*ROWB + 256*(s>>2) + 16*((4*(s&3)+g) ^ r) of the stage
@@ -474,9 +469,16 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     };
 
     if (n_it > 0) {
-        // prologue: NSTAGE-1 stages in flight
+        // prologue: NSTAGE-1 stages in flight, issued while the query operand is still on its way
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; ++s) issue_stage(s, s);
+        // Drain the operand loads (and with them the prologue, whose latency they share) before the
+        // streaming loop, so that hipcc never has a reason to put a vmcnt(0) inside it (the asm loads
+        // into AGPRs are not counted by hipcc at all).  The ring refills from iteration 0 on.
+        wait_vmcnt<0>();
+        settle_queries<NQ, KSTEPS, VB, ASM_PATH, 0>(bq);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
 
         int slot = 0;
         int fill_slot = NSTAGE - 1;
