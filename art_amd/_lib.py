@@ -8,13 +8,18 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libartmips.so")
+# ARTMIPS_LIBRARY names another build of the same ABI: the measurement scripts under tools/ point it at
+# lib/libartmips_diag.so, the only build that reads the ARTMIPS_* diagnostic knobs
+LIB_PATH = os.environ.get("ARTMIPS_LIBRARY") or os.path.join(_HERE, "lib", "libartmips.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libartmips_diag.so")
+NOALLOC_SCRATCH_BYTES = 64 << 20  # ARTMIPS_NOALLOC_SCRATCH_BYTES
 
 F16, BF16, F32 = 0, 1, 2
 MAX_DEVICES = 16
 MAX_K = 2048
 SORT_MAX = 8192
 PACK_TAIL = 4  # ARTMIPS_PACK_TAIL
+ID_SENTINEL = -2139062144  # 0x80808080: id slot of a row that was never uploaded (artmips.h)
 
 # every symbol include/artmips.h declares; tests check that the library exports each of them
 SYMBOLS = (
@@ -26,7 +31,9 @@ SYMBOLS = (
     "artmips_upload_scatter",
     "artmips_finalize",
     "artmips_search",
+    "artmips_search_async",
     "artmips_search_local",
+    "artmips_search_local_noalloc",
     "artmips_merge",
     "artmips_packed_words",
     "artmips_search_local_async",
@@ -96,6 +103,10 @@ def _load():
     lib.artmips_finalize.restype = i32
     lib.artmips_search.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp]
     lib.artmips_search.restype = i32
+    lib.artmips_search_async.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp, vp]
+    lib.artmips_search_async.restype = i32
+    lib.artmips_search_local_noalloc.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+    lib.artmips_search_local_noalloc.restype = i32
     lib.artmips_search_local.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, vp]
     lib.artmips_search_local.restype = i32
     lib.artmips_merge.argtypes = [i32, vp, vp, i32, i64, i32, vp, i32, vp, vp]

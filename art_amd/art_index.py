@@ -25,6 +25,8 @@ import shutil
 import numpy as np
 import torch
 
+from .flat_store import ID_SENTINEL
+
 
 def _megatron():
     """(get_args, mpu) when this runs inside ART, else (None, None)."""
@@ -235,6 +237,9 @@ class DistributedBruteForceIndex(object):
                                  % (rows.shape, self.embed_size))
             if ids.min() < -2 ** 31 or ids.max() > 2 ** 31 - 2:
                 raise ValueError("passage ids must fit in int32")
+            if np.any(ids == ID_SENTINEL):
+                raise ValueError("passage id %d is reserved by the index (its 'row not uploaded yet' marker)"
+                                 % ID_SENTINEL)
             all_ids[pos:pos + len(ids)] = ids
             pos += len(ids)
             if self.storage_dtype == torch.float16:
@@ -246,7 +251,7 @@ class DistributedBruteForceIndex(object):
         self.evidence_embeds = engine
         self.num_rows = n
         self.chunksize = -(-n // self.ngpu)
-        self.last_chunksize = n - self.chunksize * (self.ngpu - 1)
+        self.last_chunksize = max(0, n - self.chunksize * (self.ngpu - 1))  # trailing shards may be empty (N < G)
         self.indices_arr = all_ids
         self.id_map = _IdMap(all_ids)
 
@@ -276,7 +281,7 @@ class DistributedBruteForceIndex(object):
         self.evidence_embeds = engine
         self.num_rows = flat.n_rows
         self.chunksize = -(-flat.n_rows // self.ngpu)
-        self.last_chunksize = flat.n_rows - self.chunksize * (self.ngpu - 1)
+        self.last_chunksize = max(0, flat.n_rows - self.chunksize * (self.ngpu - 1))
         self.indices_arr = np.asarray(flat.ids).astype(np.int64)
         self.id_map = _IdMap(self.indices_arr)
 

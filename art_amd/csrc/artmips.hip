@@ -8,6 +8,7 @@
 #include "../../include/artmips.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,18 @@ static int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                   \
     } while (0)
 
+// Diagnostic knobs (A/B timing experiments) exist only in the diagnostic build
+// (-DARTMIPS_DIAG -> art_amd/lib/libartmips_diag.so).  The shipped library never reads the
+// environment: a stray ARTMIPS_* variable in a training job cannot change a plan or a result.
+#ifdef ARTMIPS_DIAG
+static int diag_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static inline int diag_int(const char*, int dflt) { return dflt; }
+#endif
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {
@@ -82,8 +95,21 @@ struct Shard {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;       // whole pipeline
     std::vector<hipEvent_t> ev_scan;                   // pairs around each FILTER scan
     // workspace
-    DevBuf qpad, thr, gmax, counts, lists, keys, status, qin, loc_scores, loc_ids;
+    DevBuf qpad, thr, gmax, counts, lists, keys, status, qin, loc_scores, loc_ids, loc_packed;
     int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints)
+};
+
+// Device scratch of one shard pipeline: pointers into the shard's own buffers (grown on demand), or
+// into the static scratch array of the allocation-free entry point.
+struct Workspace {
+    void* qpad = nullptr;     // [QT, dim] storage dtype (only used when the queries need converting)
+    float* thr = nullptr;     // [QT]
+    float* gmax = nullptr;    // pass 0: [QT][grid0 * 4 * topt]
+    int* counts = nullptr;    // [QT][grid * 4]
+    int2* lists = nullptr;    // [grid * nq * NT][cap]
+    u64* keys = nullptr;      // select_kernel's global key scratch (may be absent)
+    size_t keys_bytes = 0;
+    int* status = nullptr;    // 4 words (+ pad)
 };
 
 // One persistent helper thread per extra shard of a one-process / many-shards handle: the host needs
@@ -164,8 +190,11 @@ struct artmips {
     void* dl_pin[2] = {nullptr, nullptr};
     size_t dl_pin_bytes = 0;
     hipStream_t dl_stream[ARTMIPS_MAX_DEVICES][2] = {};
-    // gather buffers on slot 0 for the multi-shard merge
-    DevBuf g_scores, g_ids, m_keys, m_status;
+    // gather buffer on slot 0 for the multi-shard merge: [active shards][packed words]
+    DevBuf g_packed, m_keys, m_status;
+    int32_t* flag_host = nullptr;  // pinned + mapped: the multi-shard merge writes its status flag here
+    int32_t* flag_dev = nullptr;
+    hipEvent_t ev_src[ARTMIPS_MAX_DEVICES * 4] = {};  // upload_scatter: "batch ready", one per source device
     // stats
     float last_scan_ms = 0, last_total_ms = 0;
     int last_scan_launches = 0, last_retries = 0;
@@ -219,7 +248,9 @@ enum { MODE_GROUPMAX4 = 2 };
 template <typename T, int DIM, int NSTAGE, int AUX, int NQ = 1, int STG = 1, int NW = 4>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
-    static bool attr_done[ARTMIPS_MAX_DEVICES * 4][3] = {};
+    // set once per device and instantiation; shard worker threads may race here, which is harmless
+    // (the attribute call is idempotent) as long as the flag itself is not torn
+    static std::atomic<bool> attr_done[ARTMIPS_MAX_DEVICES * 4][3] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
@@ -312,9 +343,36 @@ static bool dim_supported(int dim, int dtype) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// static device scratch of artmips_search_local_noalloc
+// ---------------------------------------------------------------------------------------------
+// Callers that may not allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc)
+// get the per-shard workspace from this array instead of the shard's grown-on-demand buffers.  Every
+// GPU the library runs on holds its own copy until the process ends.  In host code the NAME of the
+// array is a host-side stand-in, not a device address: the address on each device is asked for once
+// (artmips_create, with that device current) and kept in g_scratch_ptr; only that pointer is ever
+// handed to kernels.
+static __device__ __align__(256) unsigned char scratch[ARTMIPS_NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[ARTMIPS_MAX_DEVICES * 4] = {};
+static std::mutex g_scratch_mutex;
+
+// with device `dev` current: look the array's address on that device up once
+static int scratch_init_device(int dev) {
+    if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev]) return 0;
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+        return fail(ARTMIPS_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", dev,
+                    hipGetErrorString(e));
+    g_scratch_ptr[dev] = ptr;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------------------------
-extern "C" int artmips_version(void) { return 1; }
+extern "C" int artmips_version(void) { return 2; }
 
 extern "C" const char* artmips_last_error(void) { return g_err; }
 
@@ -351,6 +409,10 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
             return fail(ARTMIPS_ERR_HIP, "hipGetDeviceProperties(%d) failed", s.dev);
         }
         s.n_cu = prop.multiProcessorCount;
+        if (scratch_init_device(s.dev) != 0) {
+            artmips_destroy(h);
+            return ARTMIPS_ERR_HIP;
+        }
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -360,6 +422,39 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
             return fail(ARTMIPS_ERR_HIP, "stream/event creation failed on device %d", s.dev);
         }
         memset(s.status_host, 0, 64);
+    }
+    // One process, several devices (the reference's model, art_index.py:204,254-255): queries and
+    // candidate lists travel between the shards' devices by peer copies, which need peer access.
+    for (int i = 0; i < n_dev; ++i) {
+        for (int j = 0; j < n_dev; ++j) {
+            const int a = h->sh[i].dev, b = h->sh[j].dev;
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                artmips_destroy(h);
+                return fail(ARTMIPS_ERR_UNSUPPORTED,
+                            "device %d cannot access the memory of device %d (no peer access): the "
+                            "one-process / many-devices mode needs it; use one process per GPU instead", a, b);
+            }
+            DeviceGuard g(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();  // torch or an earlier handle enabled it: fine
+            } else if (e != hipSuccess) {
+                artmips_destroy(h);
+                return fail(ARTMIPS_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", a, b,
+                            hipGetErrorString(e));
+            }
+        }
+    }
+    {
+        DeviceGuard g(h->sh[0].dev);
+        if (hipHostMalloc((void**)&h->flag_host, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h->flag_dev, h->flag_host, 0) != hipSuccess) {
+            artmips_destroy(h);
+            return fail(ARTMIPS_ERR_HIP, "pinned flag word allocation failed");
+        }
+        memset(h->flag_host, 0, 64);
     }
     *out = h;
     return 0;
@@ -377,7 +472,7 @@ extern "C" void artmips_destroy(artmips_t* h) {
         free_generation(s.live);
         free_generation(s.next);
         DevBuf* bufs[] = {&s.qpad, &s.thr, &s.gmax, &s.counts, &s.lists, &s.keys,
-                          &s.status, &s.qin, &s.loc_scores, &s.loc_ids};
+                          &s.status, &s.qin, &s.loc_scores, &s.loc_ids, &s.loc_packed};
         for (DevBuf* b : bufs) release(*b);
         for (hipEvent_t e : s.ev_scan) (void)hipEventDestroy(e);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
@@ -389,10 +484,10 @@ extern "C" void artmips_destroy(artmips_t* h) {
     }
     {
         DeviceGuard g(h->sh[0].dev);
-        release(h->g_scores);
-        release(h->g_ids);
+        release(h->g_packed);
         release(h->m_keys);
         release(h->m_status);
+        if (h->flag_host) (void)hipHostFree(h->flag_host);
         for (int i = 0; i < 2; ++i) {
             if (h->pin[i]) (void)hipHostFree(h->pin[i]);
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
@@ -404,6 +499,11 @@ extern "C" void artmips_destroy(artmips_t* h) {
         for (int b = 0; b < 2; ++b)
             if (h->dl_stream[i][b]) (void)hipStreamDestroy(h->dl_stream[i][b]);
     }
+    for (int d = 0; d < ARTMIPS_MAX_DEVICES * 4; ++d)
+        if (h->ev_src[d]) {
+            DeviceGuard g(d);
+            (void)hipEventDestroy(h->ev_src[d]);
+        }
     delete h;
 }
 
@@ -432,8 +532,12 @@ extern "C" int artmips_begin(artmips_t* h, int64_t n_rows_total) {
             if (e == hipSuccess) e = hipMalloc((void**)&s.next.ids, (size_t)s.next.n_rows * 4);
             if (e == hipSuccess) e = hipMalloc((void**)&s.next.meta, 32);
             // every id starts as ID_SENTINEL; artmips_finalize refuses a generation that still has one
-            if (e == hipSuccess) e = hipMemset(s.next.ids, 0x80, (size_t)s.next.n_rows * 4);
-            if (e == hipSuccess) e = hipMemset(s.next.meta, 0, 32);
+            // The fills run on the shard's own stream, the one the upload copies use, so that they are
+            // ordered before them (s.stream is non-blocking: the null stream orders nothing against it);
+            // the wait covers uploads that arrive on a caller's stream (upload_device / upload_scatter).
+            if (e == hipSuccess) e = hipMemsetAsync(s.next.ids, 0x80, (size_t)s.next.n_rows * 4, s.stream);
+            if (e == hipSuccess) e = hipMemsetAsync(s.next.meta, 0, 32, s.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
             if (e != hipSuccess) {
                 free_generation(s.next);
                 return fail(ARTMIPS_ERR_NOMEM, "hipMalloc of shard %d (%zu bytes) failed: %s", i, rb,
@@ -456,6 +560,10 @@ extern "C" int artmips_upload(artmips_t* h, const void* host_rows, const int32_t
     if (n_rows < 0 || h->cursor + n_rows > h->next_total)
         return fail(ARTMIPS_ERR_ARG, "upload of %lld rows at cursor %lld exceeds the %lld rows announced",
                     (long long)n_rows, (long long)h->cursor, (long long)h->next_total);
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (ids[i] == ID_SENTINEL)
+            return fail(ARTMIPS_ERR_ARG, "passage id %d is reserved (the \"row not uploaded yet\" marker)",
+                        (int)ID_SENTINEL);
     const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
     // pinned double buffer: sized for ~32 MiB of rows plus their ids
     const int64_t rows_per_buf = std::max<int64_t>(1, (32ll << 20) / (int64_t)row_bytes);
@@ -541,21 +649,33 @@ extern "C" int artmips_upload_scatter(artmips_t* h, int src_device, const void* 
     if (src_dtype < 0 || src_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad source dtype %d", src_dtype);
     if (n < 0) return fail(ARTMIPS_ERR_ARG, "n must be >= 0");
     if (n == 0) return 0;
+    // ids are stored as int32: every id this generation can hold must fit, and none may be the marker
+    if (id_base < -0x80000000LL || id_base + h->next_total - 1 > 0x7fffffffLL)
+        return fail(ARTMIPS_ERR_ARG, "passage ids [%lld, %lld] do not fit int32", (long long)id_base,
+                    (long long)(id_base + h->next_total - 1));
+    if (src_device < 0 || src_device >= ARTMIPS_MAX_DEVICES * 4)
+        return fail(ARTMIPS_ERR_ARG, "source device %d", src_device);
     hipStream_t st = (hipStream_t)stream;
     const size_t src_bytes = (size_t)n * h->dim * elem_size(src_dtype);
-    hipEvent_t ready = h->sh[0].ev_ready;
+    // Shards on another device than the batch get it through a staging copy on their own stream.
+    // Two events tie that stream to the caller's: `ready` (created on the source device, recorded on
+    // the caller's stream) lets the copy start only when the batch exists, and `ev_done` (recorded
+    // behind the copy, waited for by the caller's stream) keeps stream-ordered frees of the sources
+    // on the caller's stream behind the copy that still reads them.
     bool recorded = false;
+    const bool force_staging = diag_int("ARTMIPS_FORCE_STAGING", 0) != 0;  // diagnostic build: tests
     for (int i = 0; i < h->n_dev; ++i) {
         Shard& s = h->sh[i];
         if (s.next.n_rows == 0) continue;
         const void* rows_here = dev_rows;
         const int64_t* ids_here = dev_ids;
         hipStream_t run = st;
-        if (s.dev != src_device) {
-            // the batch lives on another GPU: bring it over xGMI once, scatter locally
+        if (s.dev != src_device || force_staging) {
             if (!recorded) {
                 DeviceGuard gsrc(src_device);
-                HIP_TRY(hipEventRecord(ready, st));
+                if (!h->ev_src[src_device])
+                    HIP_TRY(hipEventCreateWithFlags(&h->ev_src[src_device], hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(h->ev_src[src_device], st));
                 recorded = true;
             }
             DeviceGuard g(s.dev);
@@ -564,9 +684,14 @@ extern "C" int artmips_upload_scatter(artmips_t* h, int src_device, const void* 
             HIP_TRY(hipStreamSynchronize(s.stream));
             if ((rc = ensure(s.qin, src_bytes))) return rc;
             if ((rc = ensure(s.loc_ids, (size_t)n * 8))) return rc;
-            HIP_TRY(hipStreamWaitEvent(s.stream, ready, 0));
+            HIP_TRY(hipStreamWaitEvent(s.stream, h->ev_src[src_device], 0));
             HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, dev_rows, src_device, src_bytes, s.stream));
             HIP_TRY(hipMemcpyPeerAsync(s.loc_ids.p, s.dev, dev_ids, src_device, (size_t)n * 8, s.stream));
+            HIP_TRY(hipEventRecord(s.ev_done, s.stream));
+            {
+                DeviceGuard gsrc(src_device);
+                HIP_TRY(hipStreamWaitEvent(st, s.ev_done, 0));
+            }
             rows_here = s.qin.p;
             ids_here = (const int64_t*)s.loc_ids.p;
             run = s.stream;
@@ -654,10 +779,9 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     // each reloading the whole query operand (384 KiB at 256 queries) for a handful of tiles; four per
     // lane reach the same count with a quarter of the workgroups.
     p.topt = (top4_built && k > 128) ? 4 : 1;
-    if (const char* e = getenv("ARTMIPS_TOPT")) p.topt = (atoi(e) == 4 && top4_built) ? 4 : 1;
+    if (const int t = diag_int("ARTMIPS_TOPT", 0)) p.topt = (t == 4 && top4_built) ? 4 : 1;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
-    int grid_mult = 1;
-    if (const char* gm = getenv("ARTMIPS_GRID_MULT")) grid_mult = std::max(1, atoi(gm));
+    const int grid_mult = std::max(1, diag_int("ARTMIPS_GRID_MULT", 1));
     p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu) * grid_mult);
     p.grid = std::min(p.grid, MAX_LISTS / 4);  // select_kernel keeps one offset per list in LDS
     const long long tiles_per_block = (p.n_tiles + p.grid - 1) / p.grid;
@@ -679,7 +803,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     long long sample_div = (long long)std::llround(
         std::sqrt(0.45 * row_scale * (double)p.n_tiles / ((double)k * groups_per_wave)));
     sample_div = std::min<long long>(128, std::max<long long>(16, sample_div));
-    if (const char* sd = getenv("ARTMIPS_SAMPLE_DIV")) sample_div = std::max(4, atoi(sd));
+    if (const int sd = diag_int("ARTMIPS_SAMPLE_DIV", 0)) sample_div = std::max(4, sd);
     long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
     p.pass0 = (grid0 * per_wg >= k) && (sample * 4 <= p.n_tiles);
     if (p.pass0) {
@@ -711,7 +835,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
 // ARTMIPS_DEBUG_SYNC=1 (diagnostics): wait for every kernel of the pipeline and say so on stderr, so
 // that a kernel that never ends can be named.
 static bool debug_sync() {
-    static const bool on = [] { const char* e = getenv("ARTMIPS_DEBUG_SYNC"); return e && atoi(e) != 0; }();
+    static const bool on = diag_int("ARTMIPS_DEBUG_SYNC", 0) != 0;
     return on;
 }
 #define DEBUG_STEP(st, ...)                                            \
@@ -735,9 +859,10 @@ static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int
 }
 
 // Enqueue the pipeline of one query tile (<= 64 queries) on stream st of shard s.
-static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile, int q_dtype,
-                        int q_count, int k, void* out_scores, int score_dtype, int32_t* out_ids,
-                        long long out_row0, hipStream_t st, int tile_index, bool timed, int* status) {
+static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p, const void* q_tile,
+                        int q_dtype, int q_count, int k, void* out_scores, int score_dtype,
+                        int32_t* out_ids, long long out_row0, hipStream_t st, int tile_index, bool timed,
+                        int* status) {
     const Generation& gen = s.live;
     const int qt = p.nq * p.nw * 16;
     int* clear = (tile_index == 0) ? status : nullptr;  // cleared by kth / fill_thr below
@@ -746,12 +871,12 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     const void* q_src = q_tile;
     int q_rows = q_count;
     if (q_dtype != h->dtype || ((uintptr_t)q_tile & 15) != 0) {
-        if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
-        else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
-        else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, s.qpad.p, st);
+        if (h->dtype == ARTMIPS_F16) launch_pack<_Float16>(q_tile, q_dtype, q_count, qt, h->dim, ws.qpad, st);
+        else if (h->dtype == ARTMIPS_F32) launch_pack<float>(q_tile, q_dtype, q_count, qt, h->dim, ws.qpad, st);
+        else launch_pack<__bf16>(q_tile, q_dtype, q_count, qt, h->dim, ws.qpad, st);
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "pack q_count=%d qt=%d", q_count, qt);
-        q_src = s.qpad.p;
+        q_src = ws.qpad;
         q_rows = qt;
     }
 
@@ -762,11 +887,11 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
     a.qpad = q_src;
     a.q_rows = q_rows;
     a.q_count = q_count;
-    a.thr = (const float*)s.thr.p;
-    a.lists = (int2*)s.lists.p;
-    a.counts = (int*)s.counts.p;
+    a.thr = ws.thr;
+    a.lists = ws.lists;
+    a.counts = ws.counts;
     a.cap = p.cap;
-    a.gmax = (float*)s.gmax.p;
+    a.gmax = ws.gmax;
 
     if (p.pass0) {
         a.n_work = p.n_sample;
@@ -781,19 +906,29 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
         size_t kth_lds = 8;
         while (kth_lds < (size_t)n_values) kth_lds <<= 1;
         const int kth_threads = (n_values <= 4096) ? 256 : SEL_THREADS;
+        if (kth_lds * 4 > 48 * 1024) {
+            // 16,384 sample values (k in (1024, 2048]) are 64 KiB of dynamic LDS on top of the static
+            // histogram: above the default limit of a launch
+            static std::atomic<bool> kth_attr[ARTMIPS_MAX_DEVICES * 4] = {};
+            if (!kth_attr[s.dev]) {
+                HIP_TRY(hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            128 * 1024));
+                kth_attr[s.dev] = true;
+            }
+        }
         hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
-                           (const float*)s.gmax.p, n_values, p.nq, k, q_count, (float*)s.thr.p, clear);
+                           ws.gmax, n_values, p.nq, k, q_count, ws.thr, clear);
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "kth grid=%d threads=%d", qt, kth_threads);
     } else {
-        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, (float*)s.thr.p, q_count, qt, clear);
+        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, ws.thr, q_count, qt, clear);
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "fill_thr q_count=%d qt=%d", q_count, qt);
     }
 
     a.n_work = p.n_tiles;
     a.tile_stride = 1;
-    if (const char* e = getenv("ARTMIPS_ABLATE")) a.ablate = atoi(e);  // diagnostics: wrong results
+    a.ablate = diag_int("ARTMIPS_ABLATE", 0);  // diagnostic build only: results are then meaningless
     if (timed) {
         while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
             hipEvent_t e;
@@ -810,15 +945,15 @@ static int enqueue_tile(artmips* h, Shard& s, const Plan& p, const void* q_tile,
 
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.lists = (const int2*)s.lists.p;
-    sa.counts = (const int*)s.counts.p;
+    sa.lists = ws.lists;
+    sa.counts = ws.counts;
     sa.cap = p.cap;
     sa.scan_grid = p.grid;
     sa.nq = p.nq;
     sa.threads = p.nw * 64;
     sa.ids = gen.ids;
-    sa.keys_ws = (u64*)s.keys.p;
-    sa.keys_stride = (long long)(s.keys.bytes / 8 / (size_t)qt);
+    sa.keys_ws = ws.keys;
+    sa.keys_stride = (long long)(ws.keys_bytes / 8 / (size_t)qt);
     sa.k = k;
     sa.out_scores = out_scores;
     sa.score_dtype = score_dtype;
@@ -850,6 +985,10 @@ struct ShardCall {
     bool host_status = true;  // copy the status words to pinned host memory behind the pipeline
     int* status_dev = nullptr;  // 16 status words on the shard's device, 8-byte aligned; NULL = the
                                 // shard's own block (the async path raises them in the packed tail)
+    unsigned char* static_scratch = nullptr;  // allocation-free form: the workspace is carved from this
+                                              // device array (ARTMIPS_NOALLOC_SCRATCH_BYTES) instead
+                                              // of the shard's grown-on-demand buffers
+    int* status_used = nullptr;  // out: where the pipeline raises its status words
     int n_tiles_q = 0;
     std::chrono::steady_clock::time_point t_begin, t_enq;
 };
@@ -871,14 +1010,14 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     int nw = 4, nq;
     const bool wide_ok = (h->dim == 768 && h->dtype != ARTMIPS_F32);
     int want_nw = (wide_ok && c.n_q > 3 * QGROUP) ? 8 : 4;
-    if (const char* e = getenv("ARTMIPS_NW")) want_nw = (atoi(e) == 8 && wide_ok) ? 8 : 4;
+    if (const int e = diag_int("ARTMIPS_NW", 0)) want_nw = (e == 8 && wide_ok) ? 8 : 4;
     if (want_nw == 8) {
         nw = 8;
         nq = 2;
     } else {
         nq = (int)std::min<int64_t>((c.n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
     }
-    if (const char* e = getenv("ARTMIPS_MAX_NQ")) nq = std::max(1, std::min(nq, atoi(e)));
+    if (const int e = diag_int("ARTMIPS_MAX_NQ", 0)) nq = std::max(1, std::min(nq, e));
     if (nw == 8 && nq != 2) nw = 4;  // only the 8 x 2 shape is built
     const int QT = nq * nw * 16;
     const int NT = nw * 64;
@@ -886,25 +1025,66 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     Plan p = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq, nw,
                        h->dim == 768 && h->dtype != ARTMIPS_F32);
     int rc = 0;
-    if ((rc = ensure(s.qpad, (size_t)QT * h->dim * elem_size(h->dtype)))) return rc;
-    if ((rc = ensure(s.thr, (size_t)QT * 4))) return rc;
-    if ((rc = ensure(s.status, 64))) return rc;
-    if (p.pass0 && (rc = ensure(s.gmax, (size_t)p.grid0 * nq * NT * 4 * p.topt))) return rc;
-    if ((rc = ensure(s.counts, (size_t)p.grid * nq * NT * 4))) return rc;
-    const size_t list_entries = (size_t)p.grid * nq * NT * (size_t)p.cap;
-    if ((rc = ensure(s.lists, list_entries * 8))) return rc;
+    const size_t sz_qpad = (size_t)QT * h->dim * elem_size(h->dtype);
+    const size_t sz_thr = (size_t)QT * 4;
+    const size_t sz_gmax = p.pass0 ? (size_t)p.grid0 * nq * NT * 4 * p.topt : 0;
+    const size_t sz_counts = (size_t)p.grid * nq * NT * 4;
+    const size_t sz_lists = (size_t)p.grid * nq * NT * (size_t)p.cap * 8;
     // global key scratch: worst case every list of a query is full
     const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
-    if (keys_per_q > (size_t)SORT_MAX) {
-        if ((rc = ensure(s.keys, keys_per_q * 8 * (size_t)QT))) return rc;
+    const size_t sz_keys = (keys_per_q > (size_t)SORT_MAX) ? keys_per_q * 8 * (size_t)QT : 0;
+    Workspace ws;
+    if (c.static_scratch) {
+        // carve the workspace out of the static device array; nothing is allocated, and a shape that
+        // does not fit is refused before anything is launched
+        size_t off = 0;
+        auto take = [&](size_t bytes) -> void* {
+            void* at = c.static_scratch + off;
+            off += (bytes + 255) & ~(size_t)255;
+            return at;
+        };
+        ws.status = (int*)take(64);
+        ws.thr = (float*)take(sz_thr);
+        ws.qpad = take(sz_qpad);
+        ws.gmax = (float*)take(sz_gmax);
+        ws.counts = (int*)take(sz_counts);
+        ws.lists = (int2*)take(sz_lists);
+        if (off > (size_t)ARTMIPS_NOALLOC_SCRATCH_BYTES)
+            return fail(ARTMIPS_ERR_UNSUPPORTED,
+                        "this search needs %zu bytes of scratch (%lld rows, %lld queries, top-%d); the "
+                        "allocation-free entry point has %lld (ARTMIPS_NOALLOC_SCRATCH_BYTES)",
+                        off, (long long)gen.n_rows, (long long)c.n_q, c.k,
+                        (long long)ARTMIPS_NOALLOC_SCRATCH_BYTES);
+        // key scratch (needed only when one query keeps more candidates than the LDS routes hold):
+        // whatever is left; select_kernel raises status bit 1 rather than use more than it is given
+        ws.keys = (u64*)(c.static_scratch + off);
+        ws.keys_bytes = std::min(sz_keys, (size_t)ARTMIPS_NOALLOC_SCRATCH_BYTES - off);
+    } else {
+        if ((rc = ensure(s.qpad, sz_qpad))) return rc;
+        if ((rc = ensure(s.thr, sz_thr))) return rc;
+        if ((rc = ensure(s.status, 64))) return rc;
+        if (p.pass0 && (rc = ensure(s.gmax, sz_gmax))) return rc;
+        if ((rc = ensure(s.counts, sz_counts))) return rc;
+        if ((rc = ensure(s.lists, sz_lists))) return rc;
+        if (sz_keys && (rc = ensure(s.keys, sz_keys))) return rc;
+        ws.qpad = s.qpad.p;
+        ws.thr = (float*)s.thr.p;
+        ws.gmax = (float*)s.gmax.p;
+        ws.counts = (int*)s.counts.p;
+        ws.lists = (int2*)s.lists.p;
+        ws.keys = (u64*)s.keys.p;
+        ws.keys_bytes = s.keys.bytes;
+        ws.status = (int*)s.status.p;
     }
-    const bool timed = c.record_stats && h->stats_enabled;
+    // HIP-event timing creates events on first use: never on the allocation-free path
+    const bool timed = c.record_stats && h->stats_enabled && !c.static_scratch;
     if (timed) HIP_TRY(hipEventRecord(s.ev_t0, c.st));
-    int* const status = c.status_dev ? c.status_dev : (int*)s.status.p;
+    int* const status = c.status_dev ? c.status_dev : ws.status;
+    c.status_used = status;
     c.n_tiles_q = 0;
     for (int64_t q0 = 0; q0 < c.n_q; q0 += QT, ++c.n_tiles_q) {
         const int qc = (int)std::min<int64_t>(QT, c.n_q - q0);
-        rc = enqueue_tile(h, s, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
+        rc = enqueue_tile(h, s, ws, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
                           c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q, timed, status);
         if (rc) return rc;
     }
@@ -989,11 +1169,13 @@ extern "C" int artmips_search_local(artmips_t* h, int slot, const void* q_dev, i
 // still in flight on some stream never loses its scratch.
 struct MergeScratch {
     DevBuf keys, status;
-    int32_t* flag_host = nullptr;  // pinned word the merge kernel writes over the bus (merge_packed_sync)
-    int32_t* flag_dev = nullptr;   // its address as the device sees it
+    int32_t* flag_host = nullptr;  // pinned words the merge kernel writes over the bus (merge_packed_sync)
+    int32_t* flag_dev = nullptr;   // their address as the device sees them
+    unsigned next_flag = 0;        // calls take the words round-robin, so two calls in flight differ
+    std::mutex m;                  // one lock per device: a one-process caller's devices do not serialise
 };
+constexpr int MERGE_FLAG_WORDS = 64;
 static MergeScratch g_merge_scratch[ARTMIPS_MAX_DEVICES * 4];
-static std::mutex g_merge_mutex;
 
 static int run_merge(int device, const float* scores, const int32_t* ids, int n_lists, int64_t n_q,
                      int k, void* out_scores, int score_dtype, int32_t* out_ids, hipStream_t st,
@@ -1046,8 +1228,8 @@ extern "C" int artmips_merge(int device, const float* scores, const int32_t* ids
     if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
     if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
     if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
-    std::lock_guard<std::mutex> lock(g_merge_mutex);
     MergeScratch& ms = g_merge_scratch[device];
+    std::lock_guard<std::mutex> lock(ms.m);
     return run_merge(device, scores, ids, n_lists, n_q, k, out_scores, score_dtype, out_ids,
                      (hipStream_t)stream, &ms.keys, &ms.status);
 }
@@ -1081,7 +1263,7 @@ extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_
     Shard& s = h->sh[slot];
     DeviceGuard g(s.dev);
     if (!in_place)
-        HIP_TRY(hipMemcpyAsync(tail, s.status.p, ARTMIPS_PACK_TAIL * 4, hipMemcpyDeviceToDevice, c.st));
+        HIP_TRY(hipMemcpyAsync(tail, c.status_used, ARTMIPS_PACK_TAIL * 4, hipMemcpyDeviceToDevice, c.st));
     h->host_enqueue_us = std::chrono::duration<double, std::micro>(c.t_enq - c.t_begin).count();
     h->host_sync_us = 0.0;
     h->stats_slot = slot;
@@ -1091,6 +1273,33 @@ extern "C" int artmips_search_local_async(artmips_t* h, int slot, const void* q_
     h->stats_stream = c.st;
     h->last_retries = 0;
     return 0;
+}
+
+extern "C" int artmips_search_local_noalloc(artmips_t* h, int slot, const void* q_dev, int q_dtype,
+                                            int64_t n_q, int k, int32_t* out_packed, void* stream) {
+    int rc = check_search_args(h, q_dev, q_dtype, n_q, k, out_packed, out_packed);
+    if (rc) return rc;
+    if (slot < 0 || slot >= h->n_dev) return fail(ARTMIPS_ERR_ARG, "slot %d out of range", slot);
+    const int64_t n_local = h->sh[slot].live.n_rows;
+    if (k > ARTMIPS_MAX_K && n_local > SORT_MAX)
+        return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k, ARTMIPS_MAX_K,
+                    (long long)n_local);
+    if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
+    int32_t* const tail = out_packed + 2 * n_q * (int64_t)k;
+    if ((((uintptr_t)tail) & 7) != 0)
+        return fail(ARTMIPS_ERR_ARG, "out_packed must be 8-byte aligned (its status tail is raised in place)");
+    Shard& s = h->sh[slot];
+    unsigned char* const base = (unsigned char*)g_scratch_ptr[s.dev];   // looked up in artmips_create
+    if (!base) return fail(ARTMIPS_ERR_STATE, "static scratch of device %d was never initialised", s.dev);
+    ShardCall c{slot, q_dev, q_dtype, n_q, k, out_packed, ARTMIPS_F32, out_packed + n_q * (int64_t)k,
+                (hipStream_t)stream, false};
+    c.host_status = false;
+    c.status_dev = (int*)tail;
+    c.static_scratch = base;
+    // shard_enqueue refuses a shape whose workspace exceeds the array before it launches anything;
+    // the kernels overwrite every word of the workspace they later read (thresholds, maxima, list
+    // counters, status tail), so the previous call's contents need no clearing
+    return shard_enqueue(h, c);
 }
 
 extern "C" int artmips_set_stats(artmips_t* h, int enabled) {
@@ -1116,8 +1325,8 @@ extern "C" int artmips_merge_packed(int device, const int32_t* packed, int n_lis
     if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
     const long long plane = (long long)n_q * k;
     const long long stride = 2 * plane + ARTMIPS_PACK_TAIL;
-    std::lock_guard<std::mutex> lock(g_merge_mutex);
     MergeScratch& ms = g_merge_scratch[device];
+    std::lock_guard<std::mutex> lock(ms.m);
     return run_merge(device, (const float*)packed, packed + plane, n_lists, n_q, k, out_scores, score_dtype,
                      out_ids, (hipStream_t)stream, &ms.keys, &ms.status, stride,
                      out_flag ? packed + 2 * plane : nullptr, stride, out_flag);
@@ -1133,83 +1342,103 @@ extern "C" int artmips_merge_packed_sync(int device, const int32_t* packed, int 
     if (device < 0 || device >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", device);
     const long long plane = (long long)n_q * k;
     const long long stride = 2 * plane + ARTMIPS_PACK_TAIL;
-    // the lock is held across the wait: the pinned flag word is one per device
-    std::lock_guard<std::mutex> lock(g_merge_mutex);
     MergeScratch& ms = g_merge_scratch[device];
     DeviceGuard g(device);
+    // The per-device lock covers the enqueue.  It is kept across the wait only when the merge uses
+    // the device's global key scratch (more than SORT_MAX candidates per query), which a second
+    // merge on another stream of the same device would otherwise overwrite; the flag word is this
+    // call's own (taken round-robin from a ring of pinned words).
+    std::unique_lock<std::mutex> lock(ms.m);
     if (!ms.flag_host) {
-        HIP_TRY(hipHostMalloc((void**)&ms.flag_host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&ms.flag_host, MERGE_FLAG_WORDS * 4, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&ms.flag_dev, ms.flag_host, 0));
     }
+    const unsigned slot = ms.next_flag++ % MERGE_FLAG_WORDS;
     int rc = run_merge(device, (const float*)packed, packed + plane, n_lists, n_q, k, out_scores, score_dtype,
                        out_ids, (hipStream_t)stream, &ms.keys, &ms.status, stride, packed + 2 * plane, stride,
-                       ms.flag_dev);
+                       ms.flag_dev + slot);
     if (rc) return rc;
+    if ((long long)n_lists * k <= SORT_MAX) lock.unlock();
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // kernel end makes the word visible to the host
-    *flag_host_out = *(volatile int32_t*)ms.flag_host;
+    *flag_host_out = ((volatile int32_t*)ms.flag_host)[slot];
     return 0;
 }
 
-extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
-                              void* out_scores, int score_dtype, int32_t* out_ids, void* stream) {
+// common argument checks of artmips_search / artmips_search_async; fills `used` with the shards that
+// hold rows
+static int check_global_search(artmips* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                               const void* out_scores, int score_dtype, const void* out_ids,
+                               std::vector<int>* used) {
     int rc = check_search_args(h, q_dev, q_dtype, n_q, k, out_scores, out_ids);
     if (rc) return rc;
     if (score_dtype < 0 || score_dtype > 2) return fail(ARTMIPS_ERR_ARG, "bad score dtype");
     if ((int64_t)k > h->n_rows)
         return fail(ARTMIPS_ERR_ARG, "top_k %d exceeds the %lld rows of the index", k, (long long)h->n_rows);
     if (k > SORT_MAX) return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d", k, SORT_MAX);
-    int active = 0;
     for (int i = 0; i < h->n_dev; ++i) {
-        if (h->sh[i].live.n_rows > 0) ++active;
+        if (h->sh[i].live.n_rows > 0) used->push_back(i);
         if (k > ARTMIPS_MAX_K && h->sh[i].live.n_rows > SORT_MAX)
             return fail(ARTMIPS_ERR_UNSUPPORTED, "top_k %d > %d on a shard of %lld rows", k,
                         ARTMIPS_MAX_K, (long long)h->sh[i].live.n_rows);
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (active == 1 && h->sh[0].live.n_rows > 0) {
-        ShardCall c{0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, true};
-        return search_shard(h, c);
-    }
-    // several shards driven by this one process (the reference's model, art_index.py:273-291):
-    // replicate the queries, search every shard on its own stream, bring the (score, id) lists
-    // to slot 0 and merge there.  Only Q*k*8 bytes per shard move between devices.
+    return 0;
+}
+
+// Several shards driven by this one process (the reference's model, art_index.py:273-291): every
+// shard searches on its own stream into a packed candidate list (scores | ids | status tail, the
+// layout of the SPMD exchange), the lists are brought to slot 0's device by peer copies (Q*k*8 bytes
+// per shard instead of the reference's [Q, N/G] score slabs) and merged there on the caller's stream.
+// Everything is enqueued, nothing waits for the host: the peer copy of every shard is queued behind
+// its pipeline before any shard is waited for, and the merge writes the OR of the shards' status
+// words to `flag_dev` (a device-visible int32).  A shard on slot 0's device writes its list
+// straight into the gather buffer and reads the queries where they lie.
+static int multi_enqueue(artmips* h, const std::vector<int>& used, const void* q_dev, int q_dtype,
+                         int64_t n_q, int k, void* out_scores, int score_dtype, int32_t* out_ids,
+                         int32_t* flag_dev, hipStream_t st, ShardCall* stats_call) {
     Shard& s0 = h->sh[0];
-    const auto t_entry = std::chrono::steady_clock::now();
+    int rc = 0;
     const size_t q_bytes = (size_t)n_q * h->dim * elem_size(q_dtype);
-    const size_t list_elems = (size_t)n_q * k;
+    const int64_t plane = n_q * (int64_t)k;
+    const int64_t words = 2 * plane + ARTMIPS_PACK_TAIL;   // a multiple of 2: every list is 8-byte aligned
     {
         DeviceGuard g(s0.dev);
-        if ((rc = ensure(h->g_scores, list_elems * 4 * active))) return rc;
-        if ((rc = ensure(h->g_ids, list_elems * 4 * active))) return rc;
-        HIP_TRY(hipEventRecord(s0.ev_ready, st));
+        if ((rc = ensure(h->g_packed, (size_t)words * 4 * used.size()))) return rc;
+        HIP_TRY(hipEventRecord(s0.ev_ready, st));   // the queries exist from here on
     }
-    int li = 0;
-    std::vector<int> used;
-    for (int i = 0; i < h->n_dev; ++i)
-        if (h->sh[i].live.n_rows > 0) used.push_back(i);
-    // Enqueue every shard's pipeline on its own stream first, so that the devices work at the same
-    // time; then collect them one by one.  A shard whose candidate lists overflowed is searched
-    // again on its own (larger lists) before its result is shipped.
-    // Each shard's enqueue (scratch, wait for the queries' producer, peer copy of the queries, the
-    // pipeline) is one job: the first shard's runs here, the others on their worker threads
-    // (ARTMIPS_ENQUEUE_THREADS=0: all of them here, one after the other).
+    int32_t* const gathered = (int32_t*)h->g_packed.p;
+    // Each shard's enqueue (wait for the queries' producer, peer copy of the queries, the pipeline,
+    // peer copy of its list) is one job: the first shard's runs here, the others on their worker
+    // threads, because planning + enqueuing a pipeline costs the host ~19 us and one thread would
+    // start the eighth GPU ~135 us after the first.
     std::vector<ShardCall> calls(used.size());
-    auto enqueue_one = [h, q_dev, q_dtype, n_q, k, q_bytes, list_elems, &s0, &calls](size_t u, int slot,
-                                                                                    bool stats) -> int {
+    auto enqueue_one = [h, q_dev, q_dtype, n_q, k, q_bytes, plane, words, gathered, &s0, &calls](
+                           size_t u, int slot, bool stats) -> int {
         Shard& s = h->sh[slot];
         DeviceGuard g(s.dev);
         int r = 0;
-        if ((r = ensure(s.qin, q_bytes))) return r;
-        if ((r = ensure(s.loc_scores, list_elems * 4))) return r;
-        if ((r = ensure(s.loc_ids, list_elems * 4))) return r;
+        const bool remote = (s.dev != s0.dev);
+        const void* q_here = q_dev;
+        int32_t* list = gathered + (size_t)u * words;
         HIP_TRY(hipStreamWaitEvent(s.stream, s0.ev_ready, 0));
-        HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
-        calls[u] = ShardCall{slot, s.qin.p, q_dtype, n_q, k, s.loc_scores.p, ARTMIPS_F32,
-                             (int32_t*)s.loc_ids.p, s.stream, stats};
-        return shard_enqueue(h, calls[u]);
+        if (remote) {
+            if ((r = ensure(s.qin, q_bytes))) return r;
+            if ((r = ensure(s.loc_packed, (size_t)words * 4))) return r;
+            HIP_TRY(hipMemcpyPeerAsync(s.qin.p, s.dev, q_dev, s0.dev, q_bytes, s.stream));
+            q_here = s.qin.p;
+            list = (int32_t*)s.loc_packed.p;
+        }
+        ShardCall& c = calls[u];
+        c = ShardCall{slot, q_here, q_dtype, n_q, k, list, ARTMIPS_F32, list + plane, s.stream, stats};
+        c.status_dev = (int*)(list + 2 * plane);   // raised in the list's own tail: it travels with it
+        c.host_status = stats && h->stats_enabled;  // candidate count for artmips_info only
+        if ((r = shard_enqueue(h, c))) return r;
+        if (remote)
+            HIP_TRY(hipMemcpyPeerAsync(gathered + (size_t)u * words, s0.dev, list, s.dev, (size_t)words * 4,
+                                       s.stream));
+        HIP_TRY(hipEventRecord(s.ev_done, s.stream));
+        return 0;
     };
-    bool threaded = used.size() > 1;
-    if (const char* e = getenv("ARTMIPS_ENQUEUE_THREADS")) threaded = threaded && atoi(e) != 0;
+    const bool threaded = used.size() > 1 && diag_int("ARTMIPS_ENQUEUE_THREADS", 1) != 0;
     if (threaded) {
         if (h->workers.size() != (size_t)h->n_dev) h->workers.resize(h->n_dev);
         for (size_t u = 1; u < used.size(); ++u) {
@@ -1227,47 +1456,93 @@ extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int6
             const int r = h->workers[used[u]]->wait();
             if (r && !rc) rc = r;
         }
-        if (rc) {
-            // do not return with pipelines still running on buffers the caller may free
-            for (int i : used) { DeviceGuard g(h->sh[i].dev); (void)hipStreamSynchronize(h->sh[i].stream); }
-            return rc;
-        }
     } else {
-        for (size_t u = 0; u < used.size(); ++u)
-            if ((rc = enqueue_one(u, used[u], u == 0))) return rc;
+        for (size_t u = 0; u < used.size() && !rc; ++u) rc = enqueue_one(u, used[u], u == 0);
     }
-    const double enqueue_all_us =
-        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
-    for (ShardCall& c : calls) {
-        Shard& s = h->sh[c.slot];
-        bool overflow = false;
-        if ((rc = shard_complete(h, c, &overflow))) return rc;
-        if (overflow) {
-            if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
-            h->cap_boost *= 8;
-            if ((rc = search_shard(h, c, 1))) return rc;
-        } else if (c.record_stats) {
-            h->last_retries = 0;
-        }
-        DeviceGuard g(s.dev);
-        HIP_TRY(hipMemcpyPeerAsync((char*)h->g_scores.p + (size_t)li * list_elems * 4, s0.dev,
-                                   s.loc_scores.p, s.dev, list_elems * 4, s.stream));
-        HIP_TRY(hipMemcpyPeerAsync((char*)h->g_ids.p + (size_t)li * list_elems * 4, s0.dev,
-                                   s.loc_ids.p, s.dev, list_elems * 4, s.stream));
-        HIP_TRY(hipEventRecord(s.ev_done, s.stream));
-        ++li;
+    if (rc) {
+        // do not return with pipelines still running on buffers the caller may free
+        for (int i : used) { DeviceGuard g(h->sh[i].dev); (void)hipStreamSynchronize(h->sh[i].stream); }
+        return rc;
     }
-    {
-        DeviceGuard g(s0.dev);
-        for (int i : used) HIP_TRY(hipStreamWaitEvent(st, h->sh[i].ev_done, 0));
-    }
-    rc = run_merge(s0.dev, (const float*)h->g_scores.p, (const int32_t*)h->g_ids.p, active, n_q, k,
-                   out_scores, score_dtype, out_ids, st, &h->m_keys, &h->m_status);
-    if (rc) return rc;
+    if (stats_call) *stats_call = calls[0];
     DeviceGuard g(s0.dev);
-    HIP_TRY(hipStreamSynchronize(st));  // the search entry points return with the stream drained
-    h->host_enqueue_us = enqueue_all_us;  // entry .. last shard's pipeline enqueued (all shards)
-    return 0;
+    for (int i : used) HIP_TRY(hipStreamWaitEvent(st, h->sh[i].ev_done, 0));
+    return run_merge(s0.dev, (const float*)gathered, gathered + plane, (int)used.size(), n_q, k, out_scores,
+                     score_dtype, out_ids, st, &h->m_keys, &h->m_status, words, gathered + 2 * plane, words,
+                     flag_dev);
+}
+
+extern "C" int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                              void* out_scores, int score_dtype, int32_t* out_ids, void* stream) {
+    std::vector<int> used;
+    int rc = check_global_search(h, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, &used);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (used.size() == 1 && used[0] == 0) {
+        ShardCall c{0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, true};
+        return search_shard(h, c);
+    }
+    // One host wait per attempt: the merge leaves the OR of the shards' overflow bits in a pinned
+    // host word.  A set bit (rare: the lists are sized 8x the expectation) repeats the call with 8x
+    // larger lists on every shard; at cap == rows-per-lane overflow is impossible, so the loop ends.
+    Shard& s0 = h->sh[0];
+    int retries = 0;
+    for (;;) {
+        const auto t_entry = std::chrono::steady_clock::now();
+        ShardCall c0;
+        if ((rc = multi_enqueue(h, used, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, h->flag_dev,
+                                st, &c0)))
+            return rc;
+        const auto t_enq = std::chrono::steady_clock::now();
+        {
+            DeviceGuard g(s0.dev);
+            HIP_TRY(hipStreamSynchronize(st));  // the search entry points return with the stream drained
+        }
+        const auto t_syn = std::chrono::steady_clock::now();
+        const int flag = *(volatile int32_t*)h->flag_host;
+        if (flag & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
+        if (!(flag & 1)) {
+            h->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - t_entry).count();
+            h->host_sync_us = std::chrono::duration<double, std::micro>(t_syn - t_enq).count();
+            h->stats_slot = c0.slot;
+            h->stats_tiles = c0.n_tiles_q;
+            h->stats_pending = h->stats_enabled;
+            h->stats_async = false;
+            h->last_retries = retries;
+            if (h->stats_enabled) {
+                // the first shard's candidate count: its pipeline and the copy behind it have ended
+                // (the merge on `st` waited for them)
+                unsigned long long n = 0;
+                memcpy(&n, h->sh[c0.slot].status_host + 2, 8);
+                h->last_candidates = (int64_t)n;
+            }
+            return 0;
+        }
+        ++retries;
+        if (h->cap_boost >= (1 << 24)) return fail(ARTMIPS_ERR_STATE, "overflow retry did not converge");
+        h->cap_boost *= 8;
+    }
+}
+
+extern "C" int artmips_search_async(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                                    void* out_scores, int score_dtype, int32_t* out_ids,
+                                    int32_t* out_status, void* stream) {
+    std::vector<int> used;
+    int rc = check_global_search(h, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, &used);
+    if (rc) return rc;
+    if (!out_status || (((uintptr_t)out_status) & 7) != 0)
+        return fail(ARTMIPS_ERR_ARG, "out_status must be 4 int32 words on the device, 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h->stats_pending = false;
+    h->last_retries = 0;
+    if (used.size() == 1 && used[0] == 0) {
+        ShardCall c{0, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, st, false};
+        c.host_status = false;
+        c.status_dev = (int*)out_status;   // the kernels clear the 4 words and raise bits in word 0
+        return shard_enqueue(h, c);
+    }
+    return multi_enqueue(h, used, q_dev, q_dtype, n_q, k, out_scores, score_dtype, out_ids, out_status, st,
+                         nullptr);
 }
 
 template <typename T>
@@ -1443,13 +1718,14 @@ extern "C" int artmips_info(artmips_t* h, artmips_info_t* out) {
     out->storage_dtype = h->dtype;
     out->n_cu = h->sh[0].n_cu;
     out->n_rows = h->n_rows;
-    size_t ws = h->g_scores.bytes + h->g_ids.bytes + h->m_keys.bytes + h->m_status.bytes;
+    size_t ws = h->g_packed.bytes + h->m_keys.bytes + h->m_status.bytes;
     for (int i = 0; i < h->n_dev; ++i) {
         const Shard& s = h->sh[i];
         out->rows_per_shard[i] = s.live.n_rows;
         out->index_bytes += (int64_t)s.live.n_rows * h->dim * (int64_t)elem_size(h->dtype);
         ws += s.qpad.bytes + s.thr.bytes + s.gmax.bytes + s.counts.bytes + s.lists.bytes +
-              s.keys.bytes + s.status.bytes + s.qin.bytes + s.loc_scores.bytes + s.loc_ids.bytes;
+              s.keys.bytes + s.status.bytes + s.qin.bytes + s.loc_scores.bytes + s.loc_ids.bytes +
+              s.loc_packed.bytes;
     }
     out->workspace_bytes = (int64_t)ws;
     out->last_scan_ms = h->last_scan_ms;

@@ -161,8 +161,8 @@ struct ScanArgs {
     int* counts;          // FILTER: [64*NQ][grid*4] candidates seen by each lane (may exceed cap)
     int cap;
     float* gmax;          // GROUPMAX: [64*NQ][grid*4] running max of each lane
-    int ablate;           // diagnostics only (ARTMIPS_ABLATE, results are then meaningless):
-                          // 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
+    int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE; results are
+                          // then meaningless): 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
 };
 
 // LDS image of a stage (16 rows): the rows as they lie in memory (row-major, contiguous), cut into
@@ -368,7 +368,12 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15;  // MFMA row (row operand) / column (query operand) of this lane
     const int g = lane >> 4;  // MFMA k-group of this lane
-    const bool wave_active = (w * 16) < a.q_count && !(a.ablate & 4);   // group 0 of this wave has a real query
+#ifdef ARTMIPS_DIAG
+    const int ablate = a.ablate;   // timing experiments of the diagnostic build
+#else
+    constexpr int ablate = 0;      // the shipped library has no ablation code
+#endif
+    const bool wave_active = (w * 16) < a.q_count && !(ablate & 4);   // group 0 of this wave has a real query
     // row-operand fragments are read in NCH chunks when the query operand leaves too few registers
     constexpr int NCH = (KSTEPS >= 24) ? ((NW == 8) ? ((NQ >= 2) ? 12 : 8) : (NQ >= 4) ? 6 : 4) : 1;
     constexpr int CH = KSTEPS / NCH;
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, (const T*)a.qpad, w * 16 + r, a.q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-        thr[j] = (MODE == MODE_FILTER) ? (a.ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
+        thr[j] = (MODE == MODE_FILTER) ? (ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
     // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (long long it = 0; it < n_it; ++it) {
             // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
             wait_vmcnt<(NSTAGE - 2) * PPW>();
-            if (!(a.ablate & 2)) asm volatile("s_barrier" ::: "memory");
+            if (!(ablate & 2)) asm volatile("s_barrier" ::: "memory");
             // every wave has finished reading the slot consumed in the previous iteration: refill it.
             // On the multi-group path a working wave spreads the refill over its compute phase
             // (mg_compute) when the tile is whole; otherwise all pieces go out here.
@@ -495,13 +500,13 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 long long wk = b + (it + NSTAGE - 1) * grid;
                 if (wk > last_work) wk = last_work;
                 const long long row0 = wk * stride * TILE_ROWS;
-                dma.on = wave_active && (row0 + TILE_ROWS <= n_rows) && !(a.ablate & 1);
+                dma.on = wave_active && (row0 + TILE_ROWS <= n_rows) && !(ablate & 1);
                 dma.tile = (const char*)rows + row0 * ROWB;
                 dma.lane_off = lane_off;
                 dma.dst0 = lds_base + (uint32_t)(fill_slot * STAGE_BYTES + w * PPW * 1024);
                 dma.late = (w >= NW / 2);
             }
-            if (!dma.on && !(a.ablate & 1)) issue_stage(it + NSTAGE - 1, fill_slot);
+            if (!dma.on && !(ablate & 1)) issue_stage(it + NSTAGE - 1, fill_slot);
             fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
 
             if (wave_active) {
@@ -948,11 +953,6 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     __syncthreads();
     const bool in_lds = (M <= SORT_MAX);
     u64* gk = a.keys_ws + (size_t)q * a.keys_stride;
-    if (!in_lds && (long long)M > a.keys_stride) {
-        // cannot happen when the host sized the scratch as lists*cap; report instead of faulting
-        if (tid == 0) atomicOr(a.status, 2);
-        return;
-    }
     // list holding candidate e (binary search over the offsets): loff[lo] <= e < loff[lo + 1]
     auto find_list = [&](int e) -> int {
         int lo = 0, hi = L;
@@ -1013,6 +1013,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
 
     // ---- general routes: the keys written here are pre-keys (score, row); passage ids are looked
     // up only for the survivors
+    if (!in_lds && (long long)M > a.keys_stride) {
+        // cannot happen when the host sized the scratch as lists*cap (the allocation-free entry
+        // point hands over what its static array has left): report instead of faulting
+        if (tid == 0) atomicOr(a.status, 2);
+        return;
+    }
     u64* dst = in_lds ? skeys : gk;
     if (e_begin < e_end) {
         int lo = find_list(e_begin);

@@ -14,5 +14,9 @@ if [ "${1:-}" = "--asm" ]; then
 else
   hipcc $flags -o "$out/libartmips.so" "$here/artmips.hip"
 fi
+# the diagnostic build: the only one that reads the ARTMIPS_* environment knobs (tools/)
+hipcc $flags -DARTMIPS_DIAG -o "$out/libartmips_diag.so" "$here/artmips.hip" &
+diag_pid=$!
 hipcc $flags -o "$out/libarttok.so" "$here/arttok.hip"
-echo "built $out/libartmips.so $out/libarttok.so"
+wait $diag_pid
+echo "built $out/libartmips.so $out/libartmips_diag.so $out/libarttok.so"

@@ -138,9 +138,10 @@ class MipsEngine(object):
     def upload_scatter(self, rows, ids, id_base=1):
         """Scatter a batch of rows on a GPU (float16/bfloat16/float32, converted to the storage
         dtype) into the generation being built: the row with passage id `id` lands at global position
-        id - id_base.  Asynchronous on torch's current stream (the sources may be freed right away:
-        torch's allocator reuses memory in stream order).  Single-GPU sources only cross to other
-        devices' shards through a staging copy inside the library."""
+        id - id_base.  Asynchronous on torch's current stream.  The sources may be freed right away:
+        torch's allocator reuses memory in the order of that stream, and the library makes that stream
+        wait for the staging copies that carry the batch to shards on other devices (they run on the
+        shards' own streams) before anything queued later on it can run."""
         if not rows.is_cuda or not ids.is_cuda or rows.device != ids.device:
             raise ValueError("rows and ids must live on the same GPU")
         if ids.dtype != torch.int64:
@@ -196,6 +197,31 @@ class MipsEngine(object):
                                      _abi_dtype(score_dtype), ctypes.c_void_p(ids.data_ptr()),
                                      _stream_ptr(dev)))
         return scores, ids
+
+    def search_async(self, queries, top_k, score_dtype=torch.float16, out_status=None):
+        """search() without the host wait and without the overflow retry (artmips_search_async):
+        returns (scores, ids, status) with status a CUDA int32 [4] tensor whose word 0 is valid once
+        the current stream has passed the call (bit 0: a candidate list overflowed -> grow_lists() and
+        repeat; bit 1: internal scratch too small)."""
+        top_k = int(top_k)
+        if top_k < 1 or top_k > self.n_rows:
+            raise ValueError("top_k must be in [1, %d], got %d" % (self.n_rows, top_k))
+        q = self._check_queries(queries, self.devices[0])
+        dev = q.device
+        scores = torch.empty((q.shape[0], top_k), dtype=score_dtype, device=dev)
+        ids = torch.empty((q.shape[0], top_k), dtype=torch.int32, device=dev)
+        if out_status is None:
+            out_status = torch.empty((4,), dtype=torch.int32, device=dev)
+        elif out_status.dtype != torch.int32 or out_status.numel() < 4 or out_status.device != dev:
+            raise ValueError("out_status must be a CUDA int32 tensor of 4 words on the query's device")
+        with _on_device(dev):
+            check(lib.artmips_search_async(self._h, ctypes.c_void_p(q.data_ptr()), _abi_dtype(q.dtype),
+                                           q.shape[0], top_k, ctypes.c_void_p(scores.data_ptr()),
+                                           _abi_dtype(score_dtype), ctypes.c_void_p(ids.data_ptr()),
+                                           ctypes.c_void_p(out_status.data_ptr()), _stream_ptr(dev)))
+        if q is not queries:
+            q.record_stream(torch.cuda.current_stream(dev))
+        return scores, ids, out_status
 
     def search_local(self, slot, queries, top_k):
         """Top-k of one shard: (scores fp32 [Q,k], ids int32 [Q,k]); short shards pad with
@@ -259,6 +285,26 @@ class MipsEngine(object):
                                                  _stream_ptr(q.device)))
         if q is not queries:  # a contiguous copy the library reads after this returns: keep it alive
             q.record_stream(torch.cuda.current_stream(q.device))
+
+    def search_local_noalloc(self, slot, queries, top_k, out_packed):
+        """search_local_async for callers that cannot allocate (artmips_search_local_noalloc): the
+        shard's workspace is a static 64 MiB device array, shapes that do not fit are refused, calls
+        that overlap on one GPU race.  `queries` must be contiguous already (nothing is copied)."""
+        top_k = int(top_k)
+        if top_k < 1:
+            raise ValueError("top_k must be >= 1")
+        if not queries.is_contiguous():
+            raise ValueError("queries must be contiguous: this entry point copies nothing")
+        q = self._check_queries(queries, self.devices[slot])
+        if (out_packed.dtype != torch.int32 or not out_packed.is_cuda or not out_packed.is_contiguous()
+                or out_packed.device != q.device
+                or out_packed.numel() != self.packed_words(q.shape[0], top_k)):
+            raise ValueError("out_packed must be a contiguous CUDA int32 tensor of packed_words(Q, k) words")
+        with _on_device(q.device):
+            check(lib.artmips_search_local_noalloc(self._h, int(slot), ctypes.c_void_p(q.data_ptr()),
+                                                   _abi_dtype(q.dtype), q.shape[0], top_k,
+                                                   ctypes.c_void_p(out_packed.data_ptr()),
+                                                   _stream_ptr(q.device)))
 
     @staticmethod
     def merge_packed(packed, n_q, top_k, score_dtype=torch.float16, out_flag=None):

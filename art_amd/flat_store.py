@@ -17,6 +17,8 @@ import struct
 
 import numpy as np
 
+ID_SENTINEL = -2139062144  # 0x80808080: the index marks id slots of rows not uploaded yet with it (artmips.h)
+
 MAGIC = b"ARTFLAT1"
 HEADER_BYTES = 64
 _DT = {0: np.float16, 1: np.uint16, 2: np.float32}  # bf16 is carried as raw uint16
@@ -37,6 +39,8 @@ def write_flat(path, ids, rows, dtype_code=0):
         raise ValueError("rows dtype %s does not match dtype code %d" % (rows.dtype, dtype_code))
     if ids.size and (ids.min() < -2 ** 31 or ids.max() > 2 ** 31 - 2):
         raise ValueError("passage ids must fit in int32")
+    if np.any(ids == ID_SENTINEL):
+        raise ValueError("passage id %d is reserved by the index (its 'row not uploaded yet' marker)" % ID_SENTINEL)
     order = np.argsort(ids, kind="stable")
     ids32 = ids[order].astype(np.int32)
     if np.any(np.diff(ids32) == 0):

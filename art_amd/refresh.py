@@ -86,7 +86,7 @@ class DeviceIndexWriter(object):
         idx.evidence_embeds = self.engine
         idx.num_rows = self.n_rows
         idx.chunksize = -(-self.n_rows // idx.ngpu)
-        idx.last_chunksize = self.n_rows - idx.chunksize * (idx.ngpu - 1)
+        idx.last_chunksize = max(0, self.n_rows - idx.chunksize * (idx.ngpu - 1))
         idx.indices_arr = np.arange(self.id_base, self.id_base + self.n_rows, dtype=np.int64)
         from .art_index import _IdMap
 

@@ -99,6 +99,40 @@ def cpu_baseline(n_rows, q, k):
     }
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources: profiles/traffic.json records the value it was measured with,
+    and the bench line carries its PMC traffic figure only while the sources are still those."""
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for name in ("artmips_kernels.h", "artmips.hip"):
+        with open(os.path.join(ROOT, "art_amd", "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()
+
+
+def launcher_command(args, argv, port):
+    """`python bench.py --gpus N` without a launcher starts its own ranks: the command of the child
+    that runs torch.distributed.run with N processes on this node (the driver's own N>1 form)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """Runs BEFORE anything touches the GPU in this process (a process that has initialised the GPU
+    must not be replaced, and need not be: the ranks are children).  The parent relays the children's
+    stdout (rank 0's one JSON line) and stderr, and exits with their code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(launcher_command(args, argv, port), env=env)
+
+
 def private_stdout():
     """stdout must carry exactly ONE JSON line, but native libraries write to file descriptor 1 too
     (RCCL prints a five-line version banner there when NCCL_DEBUG=VERSION, which the GPU boxes set).
@@ -112,13 +146,14 @@ def private_stdout():
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     json_out = private_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     spmd = world > 1 or args.force_spmd
@@ -202,14 +237,24 @@ def main():
         elem = 2
         alg_bytes = (hi - lo) * DIM * elem  # bytes of rows one launch of the scan kernel must read
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters are NOT measured by this run (counters need
+        # rocprofv3 passes of their own: tools/final_profile.sh + tools/make_traffic.py write
+        # profiles/traffic.json).  The figure is carried only while the kernel sources are byte for byte
+        # the ones it was measured with, and the line says where it comes from.
         traffic = None
+        traffic_source = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 with open(tfile) as f:
                     tj = json.load(f)
-                if tj.get("rows") == hi - lo and tj.get("dtype") == args.dtype:
+                sha = kernel_source_sha()
+                if tj.get("rows") == hi - lo and tj.get("dtype") == args.dtype and tj.get("kernel_sha256") == sha:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/traffic.json@%s (rocprofv3 --pmc passes of %s)" % (
+                        sha[:12], tj.get("profile_set", "?"))
+                else:
+                    traffic_source = "none: profiles/traffic.json was measured on other kernel sources or another shape"
             except Exception:
                 traffic = None
         line = {
@@ -245,6 +290,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms_avg": scan_avg_ms,
                 "kernel_launches_timed": len(scan_ms),

@@ -16,10 +16,11 @@
  *   - device pointers are raw HIP device addresses (torch: tensor.data_ptr()).
  *   - `stream` is a hipStream_t passed as void* (torch:
  *     torch.cuda.current_stream().cuda_stream); NULL is the default stream.
- *   - all device work is enqueued on / ordered against `stream`; the search entry
- *     points synchronise that stream before they return (they must read a
- *     device status word to guarantee exactness);
- *     artmips_merge, artmips_merge_packed and artmips_search_local_async do not.
+ *   - all device work is enqueued on / ordered against `stream`; artmips_search and
+ *     artmips_search_local synchronise that stream before they return (they must read a
+ *     device status word to guarantee exactness); the *_async forms,
+ *     artmips_search_local_noalloc, artmips_merge and artmips_merge_packed only enqueue and
+ *     hand the status word to the caller instead.
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
  *   - passage ids are int32 (the reference returns int32: art_index.py:297).
  *   - a handle is used by one thread at a time (the reference drives its index from one
@@ -60,6 +61,9 @@ enum {
 #define ARTMIPS_MAX_DEVICES 16
 #define ARTMIPS_MAX_K 2048 /* for indexes larger than ARTMIPS_SORT_MAX rows */
 #define ARTMIPS_PACK_TAIL 4 /* int32 status words behind a packed candidate list */
+/* bytes of the static device array behind artmips_search_local_noalloc (held by every GPU the
+ * library runs on until the process ends) */
+#define ARTMIPS_NOALLOC_SCRATCH_BYTES (64 << 20)
 
 typedef struct artmips_info {
     int32_t n_dev;                              /* shards (one per device slot)           */
@@ -137,6 +141,17 @@ int artmips_finalize(artmips_t* h);
 int artmips_search(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
                    void* out_scores, int score_dtype, int32_t* out_ids, void* stream);
 
+/* artmips_search (art_index.py:267-304) without the host wait and without the overflow retry:
+ * everything up to the final merge is enqueued on `stream` (and, for several shards, on the shards'
+ * own streams, which `stream` then waits for) and the call returns.  out_status: 4 int32 words on
+ * the device of slot 0, 8-byte aligned, written by the kernels; once `stream` has passed the call,
+ * word 0 holds bit 0 = a candidate list overflowed (the result may have lost a top-k member: call
+ * artmips_grow_lists and repeat), bit 1 = internal scratch too small.  Queries and outputs must
+ * stay alive until `stream` has passed the call. */
+int artmips_search_async(artmips_t* h, const void* q_dev, int q_dtype, int64_t n_q, int k,
+                         void* out_scores, int score_dtype, int32_t* out_ids, int32_t* out_status,
+                         void* stream);
+
 /* One shard only: the local top-k a rank contributes in the SPMD path (one
  * process per GPU).  Outputs are fp32 scores + int32 passage ids on that shard's
  * device, ready for an RCCL all-gather.  Replaces the per-GPU matmul of
@@ -174,6 +189,19 @@ int64_t artmips_packed_words(int64_t n_q, int k);
 int artmips_search_local_async(artmips_t* h, int slot, const void* q_dev, int q_dtype, int64_t n_q,
                                int k, int32_t* out_packed, void* stream);
 
+/* artmips_search_local_async for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same packed result, bit for bit; but the shard's workspace
+ * (thresholds, pass-0 maxima, candidate lists and counters) lives in a static device array of
+ * ARTMIPS_NOALLOC_SCRATCH_BYTES (64 MiB) per GPU instead of buffers the library grows on demand, and
+ * the call performs no hipMalloc / hipFree / event creation.  A search whose workspace does not fit
+ * is refused with ARTMIPS_ERR_UNSUPPORTED before anything is launched (the ART training step fits:
+ * 64 queries x top-32 over 21M rows needs ~34 MiB; top-1000 batches do not).  out_packed must be
+ * 8-byte aligned.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (two streams, two handles, two threads) race; calls on one stream are ordered and safe. */
+int artmips_search_local_noalloc(artmips_t* h, int slot, const void* q_dev, int q_dtype, int64_t n_q,
+                                 int k, int32_t* out_packed, void* stream);
+
 /* artmips_merge over n_lists packed lists laid out back to back (what the all-gather
  * leaves).  If out_flag (device int32) is given it receives the OR of the lists'
  * status words: every rank reads the same value, so all ranks agree on a retry.
@@ -186,7 +214,8 @@ int artmips_merge_packed(int device, const int32_t* packed, int n_lists, int64_t
  * waits in its two broadcasts and .tolist(), art_model.py:361-365, evaluate.py:173-185): the merge writes the OR of
  * the lists' status words straight into a pinned host word (no device-to-host copy is
  * queued), `stream` is synchronised and the word is returned in *flag_host_out (a HOST
- * pointer).  On return the merged lists are complete.  Calls on one device are serialised. */
+ * pointer).  On return the merged lists are complete.  Calls on different devices do not
+ * serialise; on one device only their enqueue does (and the wait too when n_lists * k > 8192). */
 int artmips_merge_packed_sync(int device, const int32_t* packed, int n_lists, int64_t n_q, int k,
                               void* out_scores, int score_dtype, int32_t* out_ids,
                               int32_t* flag_host_out, void* stream);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_version_and_error_string_without_gpu():
-    assert _lib.lib.artmips_version() == 1
+    assert _lib.lib.artmips_version() == 2
     assert isinstance(_lib.lib.artmips_last_error(), bytes)
     # argument errors are reported through the status code + thread-local string, no exceptions
     rc = _lib.lib.artmips_create(None, 0, 768, 0, None)

@@ -113,3 +113,28 @@ def test_large_batch_shape_equals_training_shape(big):
     # and through four shards + merge
     s4, i4 = eng4.search(q320, 32, score_dtype=torch.float32)
     assert torch.equal(i4, i) and torch.equal(s4, s)
+
+
+def test_c3_eval_set_one_call(big):
+    """BASELINE config 3 on one GPU and on four shards of it: 3,610 queries, top-100, one call.  The first
+    64 queries are the fixture's (planted winners, reference lists); batch position must not matter
+    (bit-identical to the 64-query call) and 4 shards + merge must equal one shard everywhere."""
+    eng, eng4, queries, planted, ref_s, ref_i = big
+    g = torch.Generator(device=queries.device)
+    g.manual_seed(99)
+    more = torch.randn((3610 - 64, DIM), generator=g, device=queries.device).half()
+    q = torch.cat([queries, more], 0)
+    s, i = eng.search(q, 100, score_dtype=torch.float32)
+    info = eng.info()
+    assert info["last_retries"] == 0 and info["last_scan_launches"] == -(-3610 // 256)
+    assert bool((s[:, :-1] >= s[:, 1:]).all()) and bool((i > 0).all()) and bool((i <= N).all())
+    for j, p in enumerate(planted):
+        assert int(i[j, 0]) == p + 1
+    s64, i64 = eng.search(queries, 100, score_dtype=torch.float32)
+    assert torch.equal(i[:64], i64) and torch.equal(s[:64], s64)
+    assert bool((i.long()[:64, :32] == ref_i[:, :32]).float().mean() > 0.95)
+    s4, i4 = eng4.search(q, 100, score_dtype=torch.float32)
+    assert torch.equal(i4, i) and torch.equal(s4, s)
+    # the reference's own chunking (--shard-size 16, evaluate.py:149-160) on a slice of the set
+    outs = [eng.search(q[a:a + 16], 100, score_dtype=torch.float32) for a in range(3600 - 64, 3610, 16)]
+    assert torch.equal(torch.cat([o[1] for o in outs]), i[3600 - 64:])

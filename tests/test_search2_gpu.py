@@ -1,0 +1,266 @@
+"""GPU parity, second file: shapes and entry points added in round 2 (large k with pass 0 active, fp32
+storage at top-1000, the async search entry, the one-process / several-shards path on packed lists, the
+pipelined SPMD step on RCCL, diagnostic knobs that must NOT reach the shipped library)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mips_oracle as orc
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback for the search path")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _random_case(n, q, dim, seed, scale=0.05, dtype=np.float16):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = (rng.standard_normal((n, dim)) * scale).astype(dtype)
+    queries = rng.standard_normal((q, dim)).astype(dtype)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    return rows, queries, ids
+
+
+# ---- k in (1024, 2048] on shards where pass 0 runs (16,384 sample values: 64 KiB of dynamic LDS in
+# kth_kernel, then the score route / the global radix select at k = SUB_MAX)
+@pytest.mark.parametrize("n,q,k", [(100000, 4, 2048), (100000, 70, 1500)])
+def test_large_k_with_pass0(gu, n, q, k):
+    rows, queries, ids = _random_case(n, q, 768, seed=2000 + k)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    n_diff = orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float64), ids, k, rel_tol=REL_TOL)
+    assert n_diff <= max(2, (q * k) // 500)
+    assert eng.info()["last_retries"] == 0
+    eng.close()
+
+
+def test_k2048_integer_ties_with_pass0(gu):
+    """k == ARTMIPS_MAX_K with pass 0 active and thousands of exact ties on the k-th score: more keys
+    at or above the k-th score than the 2,048-key LDS sort holds, so the score route falls through
+    to the global radix select.  Integer data: bit-exact ids and scores."""
+    n, q, dim, k = 100000, 3, 128, 2048
+    rng = np.random.Generator(np.random.PCG64(77))
+    rows = rng.integers(-1, 2, size=(n, dim)).astype(np.float16)
+    queries = rng.integers(-1, 2, size=(q, dim)).astype(np.float16)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    es, ei, _ = orc.exact_topk(queries.astype(np.float64), rows.astype(np.float64), ids, k)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s, es.astype(np.float32))
+    eng.close()
+
+
+# ---- BASELINE config 5 at oracle size: fp32 storage, top-1000, more than one query tile (the fp32
+# scan stages survivors in LDS and flushes them many times per lane at this k)
+@pytest.mark.parametrize("n,q,k", [(30000, 150, 1000), (120000, 70, 1000)])
+def test_fp32_storage_top1000(gu, n, q, k):
+    rows, queries, ids = _random_case(n, q, 768, seed=3000 + n, dtype=np.float32)
+    eng = gu.build_engine(rows, ids, storage=torch.float32)
+    s, i = gu.search_np(eng, queries, k, q_dtype=torch.float32)
+    n_diff = orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float64), ids, k, rel_tol=1e-5)
+    assert n_diff <= max(2, (q * k) // 2000)
+    assert eng.info()["last_retries"] == 0
+    # the same rows stored as bf16: within 1e-3 relative of the exact scores of the bf16 data
+    eb = gu.build_engine(rows, ids, storage=torch.bfloat16)
+    sb, ib = gu.search_np(eb, queries, k, q_dtype=torch.float32)
+    orc.check_topk(sb, ib, orc.to_storage(queries, "bf16"), orc.to_storage(rows, "bf16"), ids, k, rel_tol=REL_TOL)
+    eng.close()
+    eb.close()
+
+
+# ---- artmips_search_async: same lists as artmips_search, status word 0 clean, one and several shards
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_search_async_matches_search(gu, n_shards):
+    rows, queries, ids = _random_case(50000, 70, 768, seed=4000 + n_shards)
+    eng = gu.build_engine(rows, ids, devices=[0] * n_shards)
+    q = torch.from_numpy(queries).cuda()
+    want_s, want_i = eng.search(q, 40, score_dtype=torch.float32)
+    status = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+    s, i, st = eng.search_async(q, 40, score_dtype=torch.float32, out_status=status)
+    torch.cuda.synchronize()
+    assert int(st[0].item()) == 0
+    assert torch.equal(i, want_i) and torch.equal(s, want_s)
+    orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64), ids, 40,
+                   rel_tol=REL_TOL)
+    eng.close()
+
+
+def test_search_async_reports_overflow(gu):
+    # the adversarial input of test_overflow_retry_is_exact: the async entry must raise bit 0 and,
+    # after grow_lists(), give the exact answer
+    n, dim, k = 131072, 768, 8
+    rng = np.random.Generator(np.random.PCG64(11))
+    rows = (rng.standard_normal((n, dim)) * 0.05).astype(np.float16)
+    queries = rng.standard_normal((2, dim)).astype(np.float16)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    tiles = np.arange(n // 16)
+    for t in tiles[tiles % 8 == 0]:
+        rows[t * 16:(t + 1) * 16] = 0
+    for n_shards in (1, 2):
+        eng = gu.build_engine(rows, ids, devices=[0] * n_shards)
+        q = torch.from_numpy(queries).cuda()
+        s, i, st = eng.search_async(q, k, score_dtype=torch.float32)
+        torch.cuda.synchronize()
+        tries = 0
+        while int(st[0].item()) & 1:
+            eng.grow_lists()
+            s, i, st = eng.search_async(q, k, score_dtype=torch.float32)
+            torch.cuda.synchronize()
+            tries += 1
+            assert tries < 8
+        assert tries >= 1, "this input is meant to overflow the candidate lists"
+        orc.check_topk(s.cpu().numpy(), i.cpu().numpy(), queries.astype(np.float64), rows.astype(np.float64), ids, k,
+                       rel_tol=REL_TOL)
+        eng.close()
+
+
+def test_multi_shard_overflow_retry_is_exact(gu):
+    n, dim, k = 262144, 768, 8
+    rng = np.random.Generator(np.random.PCG64(12))
+    rows = (rng.standard_normal((n, dim)) * 0.05).astype(np.float16)
+    queries = rng.standard_normal((3, dim)).astype(np.float16)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    tiles = np.arange(n // 16)
+    for t in tiles[tiles % 8 == 0]:
+        rows[t * 16:(t + 1) * 16] = 0
+    eng = gu.build_engine(rows, ids, devices=[0, 0])
+    s, i = gu.search_np(eng, queries, k)
+    assert eng.info()["last_retries"] >= 1
+    orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float64), ids, k, rel_tol=REL_TOL)
+    eng.close()
+
+
+# ---- the shipped library ignores the diagnostic environment
+def test_shipped_library_ignores_diagnostic_environment(gu, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "fx_small_fp16.npz"))
+    knobs = {"ARTMIPS_ABLATE": "4", "ARTMIPS_SAMPLE_DIV": "4", "ARTMIPS_NW": "8", "ARTMIPS_MAX_NQ": "1",
+             "ARTMIPS_TOPT": "4", "ARTMIPS_GRID_MULT": "3", "ARTMIPS_ENQUEUE_THREADS": "0",
+             "ARTMIPS_FORCE_STAGING": "1"}
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)  # os.environ assignment calls putenv: C getenv would see these
+    try:
+        eng = gu.build_engine(fx["rows"], fx["ids"])
+        s, i = gu.search_np(eng, fx["queries"], 32)
+        np.testing.assert_array_equal(i, fx["ids_k32"])
+        np.testing.assert_allclose(s, fx["scores_k32"], rtol=REL_TOL, atol=1e-6)
+        eng.close()
+        rows, queries, ids = _random_case(60000, 300, 768, seed=4100)
+        eng = gu.build_engine(rows, ids)
+        s, i = gu.search_np(eng, queries, 20)
+        orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float64), ids, 20, rel_tol=REL_TOL)
+        eng.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    from art_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        blob = f.read()
+    assert b"ARTMIPS_ABLATE" not in blob and b"ARTMIPS_SAMPLE_DIV" not in blob
+
+
+def test_scatter_staging_path_in_diagnostic_build():
+    """The cross-device branch of artmips_upload_scatter (staging copy on the shard's stream, tied to
+    the caller's stream by two events) cannot occur naturally on a one-GPU box: the diagnostic build
+    forces it (ARTMIPS_FORCE_STAGING) for shards on the batch's own device, in a process of its own."""
+    code = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from art_amd import _lib
+assert _lib.LIB_PATH.endswith("libartmips_diag.so")
+from art_amd.engine import MipsEngine
+n, dim = 5000, 768
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+eng = MipsEngine(dim, torch.float16, [0, 0])
+eng.begin(n)
+perm = torch.randperm(n, generator=torch.Generator().manual_seed(6)).cuda()
+keep = []
+for off in range(0, n, 700):
+    ids = perm[off:off + 700] + 1
+    rows = torch.randn((ids.shape[0], dim), generator=g, device="cuda")
+    keep.append((ids.cpu(), rows.half().cpu()))
+    eng.upload_scatter(rows, ids, id_base=1)
+    del rows, ids
+    # memory the allocator hands out right away on the caller's stream: must not disturb the copies
+    junk = torch.full((700, dim), 123.0, device="cuda")
+    del junk
+eng.finalize()
+got_rows, got_ids = eng.download(0, n)
+want = np.zeros((n, dim), dtype=np.float16)
+for ids, rows in keep:
+    want[ids.numpy() - 1] = rows.numpy()
+assert np.array_equal(got_ids, np.arange(1, n + 1, dtype=np.int32))
+assert np.array_equal(got_rows, want)
+eng.close()
+print("staging ok")
+''' % ROOT
+    env = dict(os.environ)
+    env["ARTMIPS_LIBRARY"] = os.path.join(ROOT, "art_amd", "lib", "libartmips_diag.so")
+    env["ARTMIPS_FORCE_STAGING"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "staging ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- the pipelined large-batch SPMD step on the RCCL backend (async collectives, work.wait(),
+# per-chunk merges), one rank: against the oracle, against the one-exchange step, and with an
+# overflow flag injected into one chunk (every chunk must be repeated, exactly once)
+def test_spmd_pipelined_nccl_world1(gu):
+    import torch.distributed as dist
+    from art_amd.distributed import SpmdSearcher
+    from art_amd.engine import MipsEngine
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29741")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        rows, queries, ids = _random_case(40000, 4096, 768, seed=4200)
+        eng = gu.build_engine(rows, ids)
+        q = torch.from_numpy(queries).cuda()
+        k = 1000
+        piped = SpmdSearcher(eng, always_gather=True, chunk_queries=1024)
+        s1, i1 = piped.search(q, k, score_dtype=torch.float32)
+        assert piped.last_retries == 0
+        one = SpmdSearcher(eng, always_gather=True, chunk_queries=8192)
+        s2, i2 = one.search(q, k, score_dtype=torch.float32)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+        sub = slice(0, 4096, 97)
+        orc.check_topk(s1[sub].cpu().numpy(), i1[sub].cpu().numpy(), queries[sub].astype(np.float64),
+                       rows.astype(np.float64), ids, k, rel_tol=REL_TOL)
+        # inject "some rank's lists overflowed" into the second chunk of the first attempt
+        real = MipsEngine.merge_packed_sync
+        calls = {"n": 0}
+
+        def flaky(packed, n_q, top_k, score_dtype=torch.float16):
+            s, i, st = real(packed, n_q, top_k, score_dtype)
+            calls["n"] += 1
+            return s, i, (st | 1) if calls["n"] == 2 else st
+
+        MipsEngine.merge_packed_sync = staticmethod(flaky)
+        try:
+            s3, i3 = piped.search(q, k, score_dtype=torch.float32)
+        finally:
+            MipsEngine.merge_packed_sync = staticmethod(real)
+        assert piped.last_retries == 1 and calls["n"] == 8  # 4 chunks, twice
+        assert torch.equal(i3, i1) and torch.equal(s3, s1)
+        eng.close()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -1,5 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export ARTMIPS_LIBRARY=$R/art_amd/lib/libartmips_diag.so  # the knobs below exist only in the diagnostic build
 for cfg in "4 4 0" "4 4 1" "4 4 4" "8 2 0" "8 2 1"; do
   set -- $cfg
   export ARTMIPS_NW=$1 ARTMIPS_MAX_NQ=$2 ARTMIPS_ABLATE=$3
