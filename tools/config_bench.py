@@ -19,7 +19,7 @@ which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c3", "c4", "c5"]
 dev = torch.device("cuda", 0)
 
 
-def run(tag, eng, q, k, chunk=None, reps=2):
+def run(tag, eng, q, k, chunk=None, reps=2, elem=2, peak=2500.0, per_sweep=256):
     n_rows = eng.n_rows
     def once():
         if chunk is None:
@@ -42,16 +42,15 @@ def run(tag, eng, q, k, chunk=None, reps=2):
         # peak, and the HBM traffic of ceil(Q/256) sweeps against the HBM peak
         scan_s = info["last_scan_ms"] * 1e-3
         sweeps = info["last_scan_launches"]
-        elem = 2
         roof = {"bound": "mfma", "kernel": "scan_kernel<FILTER>, %d sweeps" % sweeps,
-                "kernel_s_total": scan_s, "achieved": flops / scan_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": flops / scan_s / 2.5e15,
+                "kernel_s_total": scan_s, "achieved": flops / scan_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / scan_s / (peak * 1e12),
                 "hbm_achieved_GBs": sweeps * n_rows * 768 * elem / scan_s / 1e9,
                 "hbm_frac": sweeps * n_rows * 768 * elem / scan_s / 8e12,
                 "scan_share_of_call": scan_s / dt}
     print(json.dumps({"config": tag, "queries": q.shape[0], "top_k": k, "rows": n_rows, "chunk": chunk,
                       "seconds_per_pass": dt, "queries_per_s": q.shape[0] / dt, "tflops": flops / dt / 1e12,
-                      "frac_of_2.5PF": flops / dt / 2.5e15, "roofline": roof,
+                      "frac_of_mfma_peak": flops / dt / (peak * 1e12), "roofline": roof,
                       "index_sweeps": info["last_scan_launches"] if chunk is None else None,
                       "candidates_per_query": info["last_candidates"] / (q.shape[0] if chunk is None else min(chunk, q.shape[0])),
                       "retries": info["last_retries"]}), flush=True)
@@ -77,4 +76,12 @@ if "c5" in which:
     bench.build_shard(eng, 0, 8841823, 1234, torch.bfloat16)
     q = torch.randn((6980, 768), generator=g, device=dev).bfloat16()
     run("C5 MS MARCO scale bf16", eng, q, 1000, reps=1)
+    eng.close()
+if "c5f32" in which:
+    # BASELINE config 5's other half: the same shape with fp32 storage (exact-f32 MFMA, 157.3 TFLOP/s
+    # dense peak, 64 queries per sweep: MI355X_MICROARCH.md, Matrix cores)
+    eng = MipsEngine(768, torch.float32, [0])
+    bench.build_shard(eng, 0, 8841823, 1234, torch.float32)
+    q = torch.randn((6980, 768), generator=g, device=dev)
+    run("C5 MS MARCO scale fp32 storage", eng, q, 1000, reps=1, elem=4, peak=157.3)
     eng.close()
