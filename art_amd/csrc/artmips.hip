@@ -294,8 +294,11 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
 template <typename T, int STG>
 static int launch_scan_dt(int dim, int nq, int nw, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dim == 768 && nw == 8) {
+        // gang launches re-read every tile from the XCD's L2: default cache policy instead of nt
+        if (nq == 2 && a.gang > 1) return launch_scan_t<T, 768, 6, 0, 2, 0, 8>(mode, a, grid, st);
         if (nq == 2) return launch_scan_t<T, 768, 6, 2, 2, 0, 8>(mode, a, grid, st);
     }
+    if (a.gang > 1) return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: gang launch without an 8-wave kernel");
     if (nw != 4) return fail(ARTMIPS_ERR_UNSUPPORTED, "no %d-wave scan kernel for dim=%d nq=%d", nw, dim, nq);
     if (dim == 768) {
         if (nq == 1) {
@@ -762,6 +765,8 @@ struct Plan {
     int nw;               // waves per scan workgroup (4 or 8); a column group is 16*nw queries
     bool stage_lds;       // stage survivors in LDS (few per lane) instead of storing them directly
     int topt;             // sample values each pass-0 lane keeps per query (1, or 4 for large k)
+    int gang;             // workgroups that walk the same tiles with different query blocks (1, 2, 4);
+                          // grid and grid0 are LOGICAL (per gang member): launches use grid * gang
 };
 
 static int round_up_pow2(long long x) {
@@ -771,10 +776,11 @@ static int round_up_pow2(long long x) {
 }
 
 static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, int cap_boost, int nq, int nw,
-                      bool top4_built) {
+                      bool top4_built, int gang) {
     Plan p;
     p.nq = nq;
     p.nw = nw;
+    p.gang = gang;
     // Large k wants 8k sample values per query.  One per lane means thousands of pass-0 workgroups,
     // each reloading the whole query operand (384 KiB at 256 queries) for a handful of tiles; four per
     // lane reach the same count with a quarter of the workgroups.
@@ -782,7 +788,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     if (const int t = diag_int("ARTMIPS_TOPT", 0)) p.topt = (t == 4 && top4_built) ? 4 : 1;
     p.n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     const int grid_mult = std::max(1, diag_int("ARTMIPS_GRID_MULT", 1));
-    p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu) * grid_mult);
+    p.grid = (int)std::min<long long>(p.n_tiles, (long long)std::max(1, s.n_cu) * grid_mult / gang);
     p.grid = std::min(p.grid, MAX_LISTS / 4);  // select_kernel keeps one offset per list in LDS
     const long long tiles_per_block = (p.n_tiles + p.grid - 1) / p.grid;
     const long long cap_max = tiles_per_block * 4;  // rows one lane can ever see
@@ -792,6 +798,7 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     long long groups = std::max<long long>(1024, 8ll * k);
     const long long per_wg = 4ll * p.topt;  // sample values one pass-0 workgroup contributes per query
     long long grid0 = std::min<long long>(std::max<long long>(256, (groups + per_wg - 1) / per_wg), 8192);
+    if (gang > 1) grid0 = (grid0 + 7) / 8 * 8;  // gang members are dealt out over the 8 XCDs
     // sample = n_tiles / sample_div.  Pass 0 costs scan_time / sample_div; every survivor of the
     // filter costs scan time (a wave that keeps one holds its workgroup at the next barrier) and
     // select time, and the expected survivors per query are k * sample_div whatever the shard size.
@@ -864,7 +871,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
                         int32_t* out_ids, long long out_row0, hipStream_t st, int tile_index, bool timed,
                         int* status) {
     const Generation& gen = s.live;
-    const int qt = p.nq * p.nw * 16;
+    const int qm = p.nq * p.nw * 16;   // queries per workgroup
+    const int qt = qm * p.gang;        // queries of this launch (gang members hold qm each)
     int* clear = (tile_index == 0) ? status : nullptr;  // cleared by kth / fill_thr below
     // queries already in the storage dtype are read where they lie (columns past q_count re-read the
     // last row and are never selected); anything else is converted into the padded tile first
@@ -892,13 +900,16 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     a.counts = ws.counts;
     a.cap = p.cap;
     a.gmax = ws.gmax;
+    a.gang = p.gang;
+    a.q_tile = qm;
+    a.lists_member_stride = (long long)p.grid * p.nq * (p.nw * 64) * (long long)p.cap;
 
     if (p.pass0) {
         a.n_work = p.n_sample;
         a.tile_stride = p.sample_stride;
         int rc = (p.topt == 4)
-            ? launch_scan(h->dtype, h->dim, p.nq, p.nw, false, MODE_GROUPMAX4, a, p.grid0, st)
-            : launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0, st);
+            ? launch_scan(h->dtype, h->dim, p.nq, p.nw, false, MODE_GROUPMAX4, a, p.grid0 * p.gang, st)
+            : launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_GROUPMAX, a, p.grid0 * p.gang, st);
         if (rc) return rc;
         DEBUG_STEP(st, "scan<GROUPMAX> grid=%d nq=%d nw=%d topt=%d n_work=%lld stride=%lld", p.grid0, p.nq,
                    p.nw, p.topt, a.n_work, a.tile_stride);
@@ -921,7 +932,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "kth grid=%d threads=%d", qt, kth_threads);
     } else {
-        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, ws.thr, q_count, qt, clear);
+        hipLaunchKernelGGL(fill_thr_kernel, dim3(1), dim3(256), 0, st, ws.thr, q_count, qt, clear);  // (loops over qt)
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "fill_thr q_count=%d qt=%d", q_count, qt);
     }
@@ -937,7 +948,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         }
         HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index], st));
     }
-    int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid, st);
+    int rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid * p.gang, st);
     if (rc) return rc;
     if (timed) HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
     DEBUG_STEP(st, "scan<FILTER> grid=%d nq=%d nw=%d stg=%d cap=%d tiles=%lld rows=%lld q_count=%d q_rows=%d",
@@ -951,6 +962,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     sa.scan_grid = p.grid;
     sa.nq = p.nq;
     sa.threads = p.nw * 64;
+    sa.q_member = p.gang > 1 ? qm : 0;
+    sa.lists_member_stride = a.lists_member_stride;
     sa.ids = gen.ids;
     sa.keys_ws = ws.keys;
     sa.keys_stride = (long long)(ws.keys_bytes / 8 / (size_t)qt);
@@ -1001,38 +1014,71 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     DeviceGuard g(s.dev);
     if (gen.n_rows == 0) return fail(ARTMIPS_ERR_STATE, "shard %d is empty", c.slot);
     const size_t q_row_bytes = (size_t)h->dim * elem_size(c.q_dtype);
-    // Up to 256 queries share one sweep over the rows.  Shapes (waves x column groups):
+    // The queries are cut into launches.  Shapes (waves x column groups) of one workgroup:
     //   4 x 1..3  64..192 queries, one wave per SIMD (4 x 1 is the HBM-bound training step);
     //   8 x 2     256 queries as two groups of 128: two waves per SIMD overlap one wave's DMA issue,
-    //             LDS waits and filter with the other's MFMAs (MFMA busy 45 % -> 54 %; the chip gives
-    //             most of it back as clock, 2.00 -> 1.75 GHz: profiles/r01_m_clock_ablation.json);
+    //             LDS waits and filter with the other's MFMAs;
     //   4 x 4     256 queries where no 8-wave kernel is built (dim != 768, fp32 storage).
-    int nw = 4, nq;
-    const bool wide_ok = (h->dim == 768 && h->dtype != ARTMIPS_F32);
-    int want_nw = (wide_ok && c.n_q > 3 * QGROUP) ? 8 : 4;
-    if (const int e = diag_int("ARTMIPS_NW", 0)) want_nw = (e == 8 && wide_ok) ? 8 : 4;
-    if (want_nw == 8) {
-        nw = 8;
-        nq = 2;
-    } else {
-        nq = (int)std::min<int64_t>((c.n_q + QGROUP - 1) / QGROUP, max_nq(h->dim, h->dtype));
+    // Large batches use 8 x 2 workgroups in gangs of 2 or 4 (ScanArgs::gang): the members of a gang
+    // share an XCD and walk the same tiles with different 256-query blocks, so one HBM read of the
+    // shard serves 512 or 1,024 queries and the other reads are L2 hits.  A gang is used only where it
+    // is at least three quarters full; what is left runs as smaller launches.
+    struct Launch {
+        int64_t q0;
+        int qc;
+        Plan plan;
+    };
+    const bool wide_ok = (h->dim == 768 && h->dtype != ARTMIPS_F32) && diag_int("ARTMIPS_NW", 8) == 8;
+    const int64_t shard_tiles = (gen.n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    int max_gang = 1;
+    if (wide_ok && shard_tiles >= 8ll * s.n_cu) {
+        if (s.n_cu % 32 == 0) max_gang = 4;
+        else if (s.n_cu % 16 == 0) max_gang = 2;
     }
-    if (const int e = diag_int("ARTMIPS_MAX_NQ", 0)) nq = std::max(1, std::min(nq, e));
-    if (nw == 8 && nq != 2) nw = 4;  // only the 8 x 2 shape is built
-    const int QT = nq * nw * 16;
-    const int NT = nw * 64;
+    max_gang = std::min(max_gang, std::max(1, diag_int("ARTMIPS_GANG", 4)));
+    const int nq_cap = std::max(1, diag_int("ARTMIPS_MAX_NQ", MAX_NQ));
     c.t_begin = std::chrono::steady_clock::now();
-    Plan p = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq, nw,
-                       h->dim == 768 && h->dtype != ARTMIPS_F32);
+    Launch launches[64];
+    int n_launches = 0;
+    Plan cache[8];          // plans by shape: [0..3] = 4 x (1..4), [4..6] = 8 x 2 in gangs of 1, 2, 4
+    bool have[8] = {};
+    size_t sz_qpad = 0, sz_thr = 0, sz_gmax = 0, sz_counts = 0, sz_lists = 0, sz_keys = 0;
+    std::vector<Launch> overflow_launches;   // batches of more than 64 launches (> ~16k queries)
+    for (int64_t q0 = 0; q0 < c.n_q;) {
+        const int64_t left = c.n_q - q0;
+        int nw = 4, nq = 1, gang = 1, slot_i;
+        if (wide_ok && left > 3 * QGROUP && nq_cap >= 2) {
+            nw = 8;
+            nq = 2;
+            if (max_gang >= 4 && left > 3 * 256) gang = 4;
+            else if (max_gang >= 2 && left > 256 + 128) gang = 2;
+            slot_i = gang == 4 ? 6 : gang == 2 ? 5 : 4;
+        } else {
+            nq = (int)std::min<int64_t>((left + QGROUP - 1) / QGROUP, std::min(nq_cap, max_nq(h->dim, h->dtype)));
+            slot_i = nq - 1;
+        }
+        if (!have[slot_i]) {
+            cache[slot_i] = make_plan(s, gen.n_rows, (size_t)h->dim * elem_size(h->dtype), c.k, h->cap_boost, nq,
+                                      nw, h->dim == 768 && h->dtype != ARTMIPS_F32, gang);
+            have[slot_i] = true;
+            const Plan& p = cache[slot_i];
+            const size_t QT = (size_t)nq * nw * 16 * gang, NT = (size_t)nw * 64;
+            sz_qpad = std::max(sz_qpad, QT * h->dim * elem_size(h->dtype));
+            sz_thr = std::max(sz_thr, QT * 4);
+            if (p.pass0) sz_gmax = std::max(sz_gmax, (size_t)gang * p.grid0 * nq * NT * 4 * p.topt);
+            sz_counts = std::max(sz_counts, (size_t)gang * p.grid * nq * NT * 4);
+            sz_lists = std::max(sz_lists, (size_t)gang * p.grid * nq * NT * (size_t)p.cap * 8);
+            // global key scratch: worst case every list of a query is full
+            const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
+            if (keys_per_q > (size_t)SORT_MAX) sz_keys = std::max(sz_keys, keys_per_q * 8 * QT);
+        }
+        const int qc = (int)std::min<int64_t>(left, (int64_t)nq * nw * 16 * gang);
+        const Launch l{q0, qc, cache[slot_i]};
+        if (n_launches < 64) launches[n_launches++] = l;
+        else overflow_launches.push_back(l);
+        q0 += qc;
+    }
     int rc = 0;
-    const size_t sz_qpad = (size_t)QT * h->dim * elem_size(h->dtype);
-    const size_t sz_thr = (size_t)QT * 4;
-    const size_t sz_gmax = p.pass0 ? (size_t)p.grid0 * nq * NT * 4 * p.topt : 0;
-    const size_t sz_counts = (size_t)p.grid * nq * NT * 4;
-    const size_t sz_lists = (size_t)p.grid * nq * NT * (size_t)p.cap * 8;
-    // global key scratch: worst case every list of a query is full
-    const size_t keys_per_q = (size_t)p.grid * 4 * (size_t)p.cap;
-    const size_t sz_keys = (keys_per_q > (size_t)SORT_MAX) ? keys_per_q * 8 * (size_t)QT : 0;
     Workspace ws;
     if (c.static_scratch) {
         // carve the workspace out of the static device array; nothing is allocated, and a shape that
@@ -1063,7 +1109,7 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
         if ((rc = ensure(s.qpad, sz_qpad))) return rc;
         if ((rc = ensure(s.thr, sz_thr))) return rc;
         if ((rc = ensure(s.status, 64))) return rc;
-        if (p.pass0 && (rc = ensure(s.gmax, sz_gmax))) return rc;
+        if (sz_gmax && (rc = ensure(s.gmax, sz_gmax))) return rc;
         if ((rc = ensure(s.counts, sz_counts))) return rc;
         if ((rc = ensure(s.lists, sz_lists))) return rc;
         if (sz_keys && (rc = ensure(s.keys, sz_keys))) return rc;
@@ -1082,10 +1128,11 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     int* const status = c.status_dev ? c.status_dev : ws.status;
     c.status_used = status;
     c.n_tiles_q = 0;
-    for (int64_t q0 = 0; q0 < c.n_q; q0 += QT, ++c.n_tiles_q) {
-        const int qc = (int)std::min<int64_t>(QT, c.n_q - q0);
-        rc = enqueue_tile(h, s, ws, p, (const char*)c.q_dev + (size_t)q0 * q_row_bytes, c.q_dtype, qc, c.k,
-                          c.out_scores, c.score_dtype, c.out_ids, q0, c.st, c.n_tiles_q, timed, status);
+    const int total_launches = n_launches + (int)overflow_launches.size();
+    for (int li = 0; li < total_launches; ++li, ++c.n_tiles_q) {
+        const Launch& l = li < 64 ? launches[li] : overflow_launches[li - 64];
+        rc = enqueue_tile(h, s, ws, l.plan, (const char*)c.q_dev + (size_t)l.q0 * q_row_bytes, c.q_dtype, l.qc,
+                          c.k, c.out_scores, c.score_dtype, c.out_ids, l.q0, c.st, c.n_tiles_q, timed, status);
         if (rc) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(s.ev_t1, c.st));

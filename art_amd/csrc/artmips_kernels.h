@@ -161,6 +161,16 @@ struct ScanArgs {
     int* counts;          // FILTER: [64*NQ][grid*4] candidates seen by each lane (may exceed cap)
     int cap;
     float* gmax;          // GROUPMAX: [64*NQ][grid*4] running max of each lane
+    // Gang mode (large batches): `gang` (2 or 4) workgroups that share an XCD walk the SAME tile
+    // sequence, each with its own block of q_tile queries, so that one HBM read of a tile serves
+    // gang * q_tile queries (the first reader misses, the others hit that XCD's L2: loads use the
+    // default cache policy then).  Member m of a gang uses queries [m*q_tile, (m+1)*q_tile) and the
+    // m-th region of thr / lists / counts / gmax, each region laid out as for a launch of grid/gang
+    // workgroups; with the regions back to back the per-query arrays are simply flat over
+    // gang * q_tile queries.  gang <= 1: off.
+    int gang;
+    int q_tile;           // queries per workgroup (64 * NQ * NW / 4)
+    long long lists_member_stride;  // int2 entries between the list regions of two members
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE; results are
                           // then meaningless): 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
 };
@@ -373,7 +383,35 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #else
     constexpr int ablate = 0;      // the shipped library has no ablation code
 #endif
-    const bool wave_active = (w * 16) < a.q_count && !(ablate & 4);   // group 0 of this wave has a real query
+    // ---- which tiles, which queries (gang mode: see ScanArgs)
+    long long b = blockIdx.x;       // logical workgroup index: tiles b, b + grid, ...
+    long long grid = gridDim.x;     // logical grid
+    int q_count = a.q_count, q_rows = a.q_rows;
+    const T* qbase = (const T*)a.qpad;
+    const float* thr_base = a.thr;
+    int2* lists_base = a.lists;
+    size_t per_query_off = 0;       // into counts / gmax: (first query of this member) * values per query
+    if (a.gang > 1) {
+        // workgroups b and b + 8 run on the same XCD under round-robin dispatch (a speed assumption
+        // only: any placement gives the same results)
+        const int xcd = (int)(b & 7), l = (int)(b >> 3);
+        const int member = l % a.gang, grp = l / a.gang;
+        grid = grid / a.gang;
+        b = (long long)grp * 8 + xcd;
+        const int q0 = member * a.q_tile;
+        q_count = a.q_count - q0;
+        if (q_count > a.q_tile) q_count = a.q_tile;
+        if (q_count > 0) {
+            q_rows = a.q_rows - q0;
+            qbase += (size_t)q0 * DIM;
+        } else {
+            q_count = 0;            // a member without queries streams along and keeps nothing
+        }
+        thr_base += q0;
+        lists_base += (size_t)member * (size_t)a.lists_member_stride;
+        per_query_off = (size_t)q0;
+    }
+    const bool wave_active = (w * 16) < q_count && !(ablate & 4);   // group 0 of this wave has a real query
     // row-operand fragments are read in NCH chunks when the query operand leaves too few registers
     constexpr int NCH = (KSTEPS >= 24) ? ((NW == 8) ? ((NQ >= 2) ? 12 : 8) : (NQ >= 4) ? 6 : 4) : 1;
     constexpr int CH = KSTEPS / NCH;
@@ -392,10 +430,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     float thr[NQ];
     constexpr bool ASM_PATH = (NQ >= 2);
     constexpr bool INLINE_DMA = (NW == 8);   // refill issued between the MFMA chunks (mg_compute)
-    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, (const T*)a.qpad, w * 16 + r, a.q_rows, g);
+    load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-        thr[j] = (MODE == MODE_FILTER) ? (ablate ? INFINITY : a.thr[j * QG + w * 16 + r]) : 0.0f;
+        thr[j] = (MODE == MODE_FILTER) ? (ablate ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
     // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image
@@ -406,8 +444,6 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     const long long n_work = a.n_work;
     const long long stride = a.tile_stride;
-    const long long b = blockIdx.x;
-    const long long grid = gridDim.x;
     const long long n_it = (b < n_work) ? (n_work - b + grid - 1) / grid : 0;
     const long long last_work = n_work - 1;
 
@@ -458,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     }
     // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
     int2* const my_list = (MODE == MODE_FILTER)
-        ? a.lists + ((size_t)b * NQ * NT + tid) * (size_t)a.cap : nullptr;
+        ? lists_base + ((size_t)b * NQ * NT + tid) * (size_t)a.cap : nullptr;
     const size_t list_stride = (size_t)NT * (size_t)a.cap;  // between column groups
     // Survivors are staged in LDS (SLOTS entries per lane and column group, behind the ring) and
     // copied to the lane's list in HBM only when the staging is full and at the end of the launch.
@@ -600,7 +636,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // selection kernels read the L values of a query as one contiguous run
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const size_t o = (size_t)(j * QG + w * 16 + r) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
+        const size_t o = (per_query_off + (size_t)(j * QG + w * 16 + r)) * (size_t)(grid * 4) + (size_t)(b * 4 + g);
         if (MODE == MODE_FILTER) {
             a.counts[o] = cnt[j];
         } else {  // [query][(workgroup*4 + lane group)*TOPT + t]
@@ -758,9 +794,8 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
 
 // thresholds when pass 0 is skipped (small shards): keep everything for real queries
 __global__ void fill_thr_kernel(float* thr, int q_count, int q_tile, int* status_to_clear) {
-    const int q = threadIdx.x;
-    if (status_to_clear != nullptr && q < 4) status_to_clear[q] = 0;
-    if (q < q_tile) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
+    if (status_to_clear != nullptr && threadIdx.x < 4) status_to_clear[threadIdx.x] = 0;
+    for (int q = threadIdx.x; q < q_tile; q += blockDim.x) thr[q] = (q < q_count) ? -INFINITY : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -893,6 +928,10 @@ struct SelectArgs {
     int scan_grid;          // blocks of the FILTER scan (<= 1024)
     int nq;                 // column groups of the FILTER scan
     int threads;            // threads per workgroup of the FILTER scan (256 or 512)
+    int q_member;           // gang mode: queries per gang member (0 = no gang); query q of the launch
+                            // then belongs to member q / q_member, whose lists start
+                            // lists_member_stride entries further on
+    long long lists_member_stride;
     const int32_t* ids;     // [n_rows] passage id of each local row
     u64* keys_ws;           // [q_tile][keys_stride] global key scratch for M > SORT_MAX
     long long keys_stride;
@@ -920,9 +959,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int L = a.scan_grid * 4;  // candidate lists of this query
+    const int member = a.q_member > 0 ? q / a.q_member : 0;
+    const int ql = a.q_member > 0 ? q % a.q_member : q;   // index of the query inside its member's block
+    const int2* const lists = a.lists + (size_t)member * (size_t)a.lists_member_stride;
     auto list_of = [&](int li) -> size_t {
         const int qg = a.threads >> 2;  // queries per column group
-        return ((size_t)(li >> 2) * a.nq + q / qg) * a.threads + ((q % qg) >> 4) * 64 + (li & 3) * 16 + (q & 15);
+        return ((size_t)(li >> 2) * a.nq + ql / qg) * a.threads + ((ql % qg) >> 4) * 64 + (li & 3) * 16 + (ql & 15);
     };
     // ---- exclusive offsets of the lists: thread t owns lists [t*per, t*per+per)
     const int nt = blockDim.x;
@@ -979,7 +1021,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
             int lo = find_list(e_begin);
             for (int e = e_begin; e < e_end; ++e) {
                 while (loff[lo + 1] <= e) ++lo;
-                big[e] = f2ord(__int_as_float(a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])].x));
+                big[e] = f2ord(__int_as_float(lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])].x));
             }
         }
         __syncthreads();
@@ -998,7 +1040,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
             for (int i = tid; i < got; i += nt) {
                 const int e = (int)sub[i];
                 const int lo = find_list(e);
-                const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+                const int2 ent = lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
                 sub[i] = make_key(__int_as_float(ent.x), a.ids[ent.y]);
             }
             const int P = next_pow2(got < 2 ? 2 : got);
@@ -1024,7 +1066,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         int lo = find_list(e_begin);
         for (int e = e_begin; e < e_end; ++e) {
             while (loff[lo + 1] <= e) ++lo;
-            const int2 ent = a.lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
+            const int2 ent = lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])];
             dst[e] = ((u64)f2ord(__int_as_float(ent.x)) << 32) | (u64)(uint32_t)ent.y;
         }
     }

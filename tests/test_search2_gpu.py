@@ -62,6 +62,36 @@ def test_k2048_integer_ties_with_pass0(gu):
     eng.close()
 
 
+# ---- gang launches (2 or 4 workgroups of an XCD walk the same tiles with different 256-query blocks):
+# full gangs, a gang whose last member is nearly empty, a gang followed by smaller launches, k = 1000
+@pytest.mark.parametrize("n,q,k,storage", [
+    (70000, 1024, 100, "f16"),    # one full gang of 4
+    (70000, 800, 32, "f16"),      # gang of 4 whose fourth member holds 32 queries
+    (50000, 600, 1000, "bf16"),   # gang of 2 + 88 queries as a 4 x 2 launch, direct list writes
+    (40000, 2100, 10, "f16"),     # two gangs of 4 + 52 queries
+    (36000, 450, 50, "f16"),      # gang of 2 with 194 queries in the second member, small shard
+])
+def test_gang_launches_vs_oracle(gu, n, q, k, storage):
+    rng = np.random.Generator(np.random.PCG64(5000 + n + q))
+    rows = (rng.standard_normal((n, 768)) * 0.05).astype(np.float32)
+    queries = rng.standard_normal((q, 768)).astype(np.float32)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    tdt = torch.float16 if storage == "f16" else torch.bfloat16
+    eng = gu.build_engine(rows.astype(np.float16) if storage == "f16" else rows, ids, storage=tdt)
+    s, i = gu.search_np(eng, queries, k, q_dtype=tdt)
+    n_diff = orc.check_topk(s, i, orc.to_storage(queries, storage), orc.to_storage(rows, storage), ids, k,
+                            rel_tol=REL_TOL)
+    assert n_diff <= max(2, (q * k) // 500)
+    assert eng.info()["last_retries"] == 0
+    # batch position and launch shape must not matter: the same queries alone give the same bits
+    qd = torch.from_numpy(queries).to(tdt).cuda()
+    s_all, i_all = eng.search(qd, k, score_dtype=torch.float32)
+    for a, b in ((0, 64), (q - 40, q), (300, 364)):
+        s1, i1 = eng.search(qd[a:b], k, score_dtype=torch.float32)
+        assert torch.equal(i1, i_all[a:b]) and torch.equal(s1, s_all[a:b])
+    eng.close()
+
+
 # ---- BASELINE config 5 at oracle size: fp32 storage, top-1000, more than one query tile (the fp32
 # scan stages survivors in LDS and flushes them many times per lane at this k)
 @pytest.mark.parametrize("n,q,k", [(30000, 150, 1000), (120000, 70, 1000)])
