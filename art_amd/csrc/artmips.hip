@@ -294,11 +294,12 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
 template <typename T, int STG>
 static int launch_scan_dt(int dim, int nq, int nw, int mode, const ScanArgs& a, int grid, hipStream_t st) {
     if (dim == 768 && nw == 8) {
-        // gang launches re-read every tile from the XCD's L2: default cache policy instead of nt
         if (nq == 2 && a.gang > 1) return launch_scan_t<T, 768, 6, 0, 2, 0, 8>(mode, a, grid, st);
-        if (nq == 2) return launch_scan_t<T, 768, 6, 2, 2, 0, 8>(mode, a, grid, st);
+        if (nq == 2 && a.gang <= 1) return launch_scan_t<T, 768, 6, 2, 2, 0, 8>(mode, a, grid, st);
     }
-    if (a.gang > 1) return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: gang launch without an 8-wave kernel");
+    // gang launches re-read every tile from the XCD's L2: default cache policy instead of nt
+    if (a.gang > 1 && dim == 768 && nw == 4 && nq == 4) return launch_scan_t<T, 768, 6, 0, 4, STG>(mode, a, grid, st);
+    if (a.gang > 1) return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: no gang kernel for this shape");
     if (nw != 4) return fail(ARTMIPS_ERR_UNSUPPORTED, "no %d-wave scan kernel for dim=%d nq=%d", nw, dim, nq);
     if (dim == 768) {
         if (nq == 1) {
@@ -1018,29 +1019,38 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     //   4 x 1..3  64..192 queries, one wave per SIMD (4 x 1 is the HBM-bound training step);
     //   8 x 2     256 queries as two groups of 128: two waves per SIMD overlap one wave's DMA issue,
     //             LDS waits and filter with the other's MFMAs;
-    //   4 x 4     256 queries where no 8-wave kernel is built (dim != 768, fp32 storage).
-    // Large batches use 8 x 2 workgroups in gangs of 2 or 4 (ScanArgs::gang): the members of a gang
-    // share an XCD and walk the same tiles with different 256-query blocks, so one HBM read of the
-    // shard serves 512 or 1,024 queries and the other reads are L2 hits.  A gang is used only where it
-    // is at least three quarters full; what is left runs as smaller launches.
+    //   4 x 4     256 queries, one wave per SIMD holding 64 queries: half the LDS read bytes per flop
+    //             of 8 x 2.  Used where no 8-wave kernel is built (dim != 768) and in gangs.
+    // Large batches run in gangs of 2, 4 or 8 workgroups (ScanArgs::gang): the members of a gang share
+    // an XCD and walk the same tiles with different 256-query blocks, so one HBM read of the shard
+    // serves 512 ... 2,048 queries and the other reads are L2 hits.  With the HBM traffic gone the
+    // regime is limited by power, and for small k the 4 x 4 shape (fewer LDS bytes per flop) is the
+    // faster one there: 2,048 queries x top-100 over 21M rows 62.9 ms as 8 x 2 in gangs of 4, 60.6 in
+    // gangs of 8; 59.7 / 58.2 ms as 4 x 4 (without gangs 68.3 / 68.7).  At top-1000 every lane writes
+    // survivors all the time and two waves per SIMD hide that better: 8 x 2 in gangs of 8 62.9 ms,
+    // 4 x 4 63.1 ms (27.5 vs 29.1 ms on 8.8M rows) (profiles/r02_c_gang_shapes.txt).  A gang is used
+    // only where it is at least ~7/8 full; what is left runs as smaller launches.
     struct Launch {
         int64_t q0;
         int qc;
         Plan plan;
     };
-    const bool wide_ok = (h->dim == 768 && h->dtype != ARTMIPS_F32) && diag_int("ARTMIPS_NW", 8) == 8;
+    const bool gang_dim = (h->dim == 768 && h->dtype != ARTMIPS_F32);
+    const int nw_knob = diag_int("ARTMIPS_NW", 8);   // diagnostic build: 4 = no wide shapes, 88 / 44 = gangs of 8 x 2 / 4 x 4 whatever k
+    const bool wide_ok = gang_dim && nw_knob != 4;
     const int64_t shard_tiles = (gen.n_rows + TILE_ROWS - 1) / TILE_ROWS;
     int max_gang = 1;
     if (wide_ok && shard_tiles >= 8ll * s.n_cu) {
-        if (s.n_cu % 32 == 0) max_gang = 4;
+        if (s.n_cu % 64 == 0) max_gang = 8;
+        else if (s.n_cu % 32 == 0) max_gang = 4;
         else if (s.n_cu % 16 == 0) max_gang = 2;
     }
-    max_gang = std::min(max_gang, std::max(1, diag_int("ARTMIPS_GANG", 4)));
+    max_gang = std::min(max_gang, std::max(1, diag_int("ARTMIPS_GANG", 8)));
     const int nq_cap = std::max(1, diag_int("ARTMIPS_MAX_NQ", MAX_NQ));
     c.t_begin = std::chrono::steady_clock::now();
     Launch launches[64];
     int n_launches = 0;
-    Plan cache[8];          // plans by shape: [0..3] = 4 x (1..4), [4..6] = 8 x 2 in gangs of 1, 2, 4
+    Plan cache[8];          // plans by shape: [0..3] = 4 x (1..4), [4] = 8 x 2, [5..7] = gangs of 2, 4, 8
     bool have[8] = {};
     size_t sz_qpad = 0, sz_thr = 0, sz_gmax = 0, sz_counts = 0, sz_lists = 0, sz_keys = 0;
     std::vector<Launch> overflow_launches;   // batches of more than 64 launches (> ~16k queries)
@@ -1048,11 +1058,17 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
         const int64_t left = c.n_q - q0;
         int nw = 4, nq = 1, gang = 1, slot_i;
         if (wide_ok && left > 3 * QGROUP && nq_cap >= 2) {
-            nw = 8;
-            nq = 2;
-            if (max_gang >= 4 && left > 3 * 256) gang = 4;
+            if (max_gang >= 8 && left > 7 * 256) gang = 8;
+            else if (max_gang >= 4 && left > 3 * 256) gang = 4;
             else if (max_gang >= 2 && left > 256 + 128) gang = 2;
-            slot_i = gang == 4 ? 6 : gang == 2 ? 5 : 4;
+            if (gang > 1 && nw_knob != 88 && (c.k <= 128 || nw_knob == 44)) {
+                nw = 4;
+                nq = 4;
+            } else {
+                nw = 8;
+                nq = 2;
+            }
+            slot_i = gang == 8 ? 7 : gang == 4 ? 6 : gang == 2 ? 5 : 4;
         } else {
             nq = (int)std::min<int64_t>((left + QGROUP - 1) / QGROUP, std::min(nq_cap, max_nq(h->dim, h->dtype)));
             slot_i = nq - 1;

@@ -43,6 +43,12 @@ enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
 // ---------------------------------------------------------------------------------------------
 // element helpers
 // ---------------------------------------------------------------------------------------------
+// hazard pad in front of every inline-asm MFMA (see Elem<>::mfma_asm)
+#ifdef ARTMIPS_NO_MFMA_PAD
+#define ARTMIPS_MFMA_PAD ""
+#else
+#define ARTMIPS_MFMA_PAD "s_nop 1\n\t"
+#endif
 template <typename T> struct Elem;
 template <> struct Elem<_Float16> {
     typedef half8 V;
@@ -56,11 +62,11 @@ template <> struct Elem<_Float16> {
     template <bool B_AGPR, bool FIRST>
     static __device__ __forceinline__ void mfma_asm(f32x4& c, const V& a, const V& b) {
         if constexpr (FIRST) {
-            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+            if constexpr (B_AGPR) asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+            else asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
         } else {
-            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+            if constexpr (B_AGPR) asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+            else asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
         }
     }
 };
@@ -73,11 +79,11 @@ template <> struct Elem<__bf16> {
     template <bool B_AGPR, bool FIRST>
     static __device__ __forceinline__ void mfma_asm(f32x4& c, const V& a, const V& b) {
         if constexpr (FIRST) {
-            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+            if constexpr (B_AGPR) asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+            else asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
         } else {
-            if constexpr (B_AGPR) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+            if constexpr (B_AGPR) asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+            else asm volatile(ARTMIPS_MFMA_PAD "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
         }
     }
 };
@@ -271,6 +277,8 @@ struct MgDma {
     uint32_t dst0;           // uniform: LDS address of this wave's first piece
     bool on;                 // uniform: false = the caller issued the stage itself
     bool late;               // uniform: this wave issues in the second half of the phase
+    bool noread;             // diagnostic build only (ARTMIPS_ABLATE & 8): skip the LDS reads and waits
+    bool nowait;             // diagnostic build only (ARTMIPS_ABLATE & 32): issue the LDS reads, never wait
 };
 template <int AUX, int PPW, int NCH, int NW, int C, int PP>
 __device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
@@ -290,12 +298,14 @@ template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int AUX, int 
 __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq)[KSTEPS],
                                            const uint32_t (&base)[4], const MgDma& d) {
     if constexpr (C < NCH) {
-        if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
-        if constexpr (C + 1 < NCH) {
-            mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
-            mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
-        } else {
-            mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
+        if (!d.noread) {
+            if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
+            if constexpr (C + 1 < NCH) {
+                mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
+                if (!d.nowait) mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
+            } else {
+                if (!d.nowait) mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
+            }
         }
         mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, 0>(d);
@@ -429,7 +439,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     V bq[NQ][KSTEPS];
     float thr[NQ];
     constexpr bool ASM_PATH = (NQ >= 2);
-    constexpr bool INLINE_DMA = (NW == 8);   // refill issued between the MFMA chunks (mg_compute)
+    // refill issued between the MFMA chunks (mg_compute) instead of in one burst behind the barrier
+    // (tried for the 4 x 4 shape too: one piece behind each of its six chunks was 5 % slower than the burst)
+    constexpr bool INLINE_DMA = (NW == 8);
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
@@ -532,6 +544,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             // (mg_compute) when the tile is whole; otherwise all pieces go out here.
             MgDma dma;
             dma.on = false;
+            dma.noread = (ablate & 8) != 0;
+            dma.nowait = (ablate & 32) != 0;
             if constexpr (ASM_PATH && INLINE_DMA) {
                 long long wk = b + (it + NSTAGE - 1) * grid;
                 if (wk > last_work) wk = last_work;
@@ -586,7 +600,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 const long long row_base = (b + it * grid) * stride * TILE_ROWS + g * 4;
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
-                    if (MODE == MODE_FILTER) {
+                    if (ablate & 16) {
+                        asm volatile("" ::"v"(acc[j]));   // diagnostic build: no filter, scores kept live
+                    } else if (MODE == MODE_FILTER) {
                         const float m = fmaxf(fmaxf(acc[j][0], acc[j][1]), fmaxf(acc[j][2], acc[j][3]));
                         if (__builtin_amdgcn_ballot_w64(m >= thr[j]) != 0ull) {
 #pragma unroll

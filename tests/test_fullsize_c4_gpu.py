@@ -71,7 +71,7 @@ def c4():
 
 def test_c4_planted_and_reference(c4):
     eng, eng4, queries, planted, ref_s, ref_i, (s, i), info = c4
-    assert info["last_retries"] == 0 and info["last_scan_launches"] == Q // 1024  # gangs of 4 x 256 queries
+    assert info["last_retries"] == 0 and info["last_scan_launches"] == Q // 2048  # gangs of 8 x 256 queries
     assert tuple(s.shape) == (Q, K) and i.dtype == torch.int32
     assert bool((s[:, :-1] >= s[:, 1:]).all())
     assert bool((i > 0).all()) and bool((i <= N).all())

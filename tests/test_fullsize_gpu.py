@@ -126,8 +126,8 @@ def test_c3_eval_set_one_call(big):
     q = torch.cat([queries, more], 0)
     s, i = eng.search(q, 100, score_dtype=torch.float32)
     info = eng.info()
-    # 3 gangs of 4 x 256 queries, one gang of 2 x 256, and the last 26 queries on their own
-    assert info["last_retries"] == 0 and info["last_scan_launches"] == 5
+    # gangs of 8, 4 and 2 workgroups x 256 queries (2,048 + 1,024 + 512), and the last 26 queries on their own
+    assert info["last_retries"] == 0 and info["last_scan_launches"] == 4
     assert bool((s[:, :-1] >= s[:, 1:]).all()) and bool((i > 0).all()) and bool((i <= N).all())
     for j, p in enumerate(planted):
         assert int(i[j, 0]) == p + 1

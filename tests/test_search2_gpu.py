@@ -68,7 +68,8 @@ def test_k2048_integer_ties_with_pass0(gu):
     (70000, 1024, 100, "f16"),    # one full gang of 4
     (70000, 800, 32, "f16"),      # gang of 4 whose fourth member holds 32 queries
     (50000, 600, 1000, "bf16"),   # gang of 2 + 88 queries as a 4 x 2 launch, direct list writes
-    (40000, 2100, 10, "f16"),     # two gangs of 4 + 52 queries
+    (40000, 2100, 10, "f16"),     # one gang of 8 (2,048 queries) + 52 queries
+    (60000, 1900, 1000, "bf16"),  # gang of 8 whose last member holds 108 queries, k = 1000
     (36000, 450, 50, "f16"),      # gang of 2 with 194 queries in the second member, small shard
 ])
 def test_gang_launches_vs_oracle(gu, n, q, k, storage):

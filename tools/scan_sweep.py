@@ -26,6 +26,7 @@ p.add_argument("--queries", type=int, default=64)
 p.add_argument("--topk", type=int, default=32)
 p.add_argument("--nq-sweep", action="store_true", help="variants are values of ARTMIPS_MAX_NQ (1..4)")
 p.add_argument("--env", default=None, help="variants are values of this environment variable")
+p.add_argument("--envs", action="store_true", help="variants are NAME=VAL+NAME=VAL settings of several knobs")
 p.add_argument("--shape-sweep", action="store_true", help="variants are NW:NQ pairs (ARTMIPS_NW, ARTMIPS_MAX_NQ)")
 args = p.parse_args()
 
@@ -44,6 +45,10 @@ for rnd in range(args.rounds + 1):
             os.environ["ARTMIPS_MAX_NQ"] = v
         if args.env:
             os.environ[args.env] = v
+        if args.envs:
+            for kv in v.split("+"):
+                name, val = kv.split("=")
+                os.environ[name] = val
         if args.shape_sweep:
             os.environ["ARTMIPS_NW"], os.environ["ARTMIPS_MAX_NQ"] = v.split(":")[:2]
             os.environ["ARTMIPS_ABLATE"] = v.split(":")[2] if v.count(":") > 1 else "0"
