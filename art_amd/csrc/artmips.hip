@@ -641,6 +641,25 @@ extern "C" int artmips_upload_device(artmips_t* h, int slot, const void* dev_row
 template <typename T>
 static void launch_scatter(const void* src, int src_dtype, const long long* ids, long long n,
                            long long id_base, const Generation& g, int dim, hipStream_t st) {
+    // 16-byte accesses when both sides allow it (every shape the index supports does; a caller's
+    // source buffer may still be unaligned), else the element-wise kernel
+    const size_t src_row = (size_t)dim * elem_size(src_dtype), dst_row = (size_t)dim * sizeof(T);
+    const bool vec = (((uintptr_t)src) & 15) == 0 && src_row % 16 == 0 && dst_row % 16 == 0 &&
+                     (((uintptr_t)g.rows) & 15) == 0 &&
+                     (sizeof(T) == 2 || src_dtype == ARTMIPS_F32 || src_row % 8 == 0);
+    if (vec) {
+        // enough workgroups for every CU even from a 1,024-row batch, 8 rows each for large ones
+        const int rpw = (int)std::max<long long>(1, std::min<long long>(8, n / 1024));
+        const int grid = (int)std::min<long long>((n + rpw - 1) / rpw, 8192);
+#define SCATTER_VEC(S)                                                                                  \
+    hipLaunchKernelGGL((scatter_rows_vec_kernel<T, S>), dim3(grid), dim3(256), 0, st, (const S*)src, ids, n, \
+                       id_base, (long long)g.row0, (long long)g.n_rows, dim, (T*)g.rows, g.ids, g.meta, rpw)
+        if (src_dtype == ARTMIPS_F16) SCATTER_VEC(_Float16);
+        else if (src_dtype == ARTMIPS_BF16) SCATTER_VEC(__bf16);
+        else SCATTER_VEC(float);
+#undef SCATTER_VEC
+        return;
+    }
     const int grid = (int)std::min<long long>(n, 4096);
     hipLaunchKernelGGL(scatter_rows_kernel<T>, dim3(grid), dim3(256), 0, st, src, src_dtype, ids, n, id_base,
                        (long long)g.row0, (long long)g.n_rows, dim, (T*)g.rows, g.ids, g.meta);

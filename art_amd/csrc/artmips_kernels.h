@@ -1186,6 +1186,58 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* __restric
     }
 }
 
+// The same scatter with 16-byte accesses: a workgroup takes rows_per_wg batch rows at a time and its
+// threads walk the (row, 16-byte output chunk) pairs of that block, so that every lane loads 16 or 32
+// source bytes and stores 16 (HBM-bound byte work: coalesced wide accesses are all there is to it).
+// Needs 16-byte aligned source and destination rows (dim * element size a multiple of 16 on both
+// sides and an aligned source base); the host falls back to scatter_rows_kernel otherwise.
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void scatter_rows_vec_kernel(const S* __restrict__ src,
+                                                               const long long* __restrict__ ids, long long n,
+                                                               long long id_base, long long shard_row0,
+                                                               long long shard_rows, int dim,
+                                                               T* __restrict__ rows, int32_t* __restrict__ row_ids,
+                                                               unsigned long long* __restrict__ meta,
+                                                               int rows_per_wg) {
+    constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte output chunk
+    const int cpr = dim / EPC;                    // chunks per row
+    const int items = rows_per_wg * cpr;
+    for (long long r0 = (long long)blockIdx.x * rows_per_wg; r0 < n; r0 += (long long)gridDim.x * rows_per_wg) {
+        for (int w = threadIdx.x; w < items; w += blockDim.x) {
+            const int lr = w / cpr, c = w - lr * cpr;
+            const long long i = r0 + lr;
+            if (i >= n) break;
+            const long long id = ids[i];
+            const long long pos = id - id_base - shard_row0;
+            if (pos < 0 || pos >= shard_rows) continue;   // another shard owns this row
+            const S* sp = src + i * dim + c * EPC;
+            float v[EPC];
+            if constexpr (sizeof(S) == 4) {
+#pragma unroll
+                for (int q = 0; q < EPC / 4; ++q) {
+                    const float4 x = ((const float4*)sp)[q];
+                    v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+                }
+            } else {
+                typedef S SV __attribute__((ext_vector_type(EPC)));
+                const SV x = *(const SV*)sp;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = (float)x[e];
+            }
+            typedef T TV __attribute__((ext_vector_type(EPC)));
+            TV o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = Elem<T>::from_float(v[e]);
+            *(TV*)(rows + pos * dim + c * EPC) = o;
+            if (c == 0) {
+                const int32_t old = atomicExch(&row_ids[pos], (int32_t)id);
+                if (old != ID_SENTINEL) atomicAdd(&meta[1], 1ull);
+                else atomicAdd(&meta[0], 1ull);
+            }
+        }
+    }
+}
+
 // how many rows of a shard were never uploaded
 __global__ void count_unfilled_kernel(const int32_t* __restrict__ row_ids, long long n,
                                       unsigned long long* __restrict__ out) {
