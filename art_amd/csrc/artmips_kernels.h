@@ -1166,6 +1166,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* __restric
                                                            long long shard_rows, int dim,
                                                            T* __restrict__ rows, int32_t* __restrict__ row_ids,
                                                            unsigned long long* __restrict__ meta) {
+    unsigned long long fresh = 0, dups = 0;   // thread 0: rows this workgroup wrote / wrote over
     for (long long i = blockIdx.x; i < n; i += gridDim.x) {
         const long long id = ids[i];
         const long long pos = id - id_base - shard_row0;
@@ -1180,9 +1181,14 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* __restric
         }
         if (threadIdx.x == 0) {
             const int32_t old = atomicExch(&row_ids[pos], (int32_t)id);
-            if (old != ID_SENTINEL) atomicAdd(&meta[1], 1ull);
-            else atomicAdd(&meta[0], 1ull);
+            if (old != ID_SENTINEL) ++dups; else ++fresh;
         }
+    }
+    // one add per workgroup: a counter every row adds to is one contended word (262,144 rows took
+    // 3 ms for that alone)
+    if (threadIdx.x == 0) {
+        if (fresh) atomicAdd(&meta[0], fresh);
+        if (dups) atomicAdd(&meta[1], dups);
     }
 }
 
@@ -1202,6 +1208,7 @@ __global__ __launch_bounds__(256) void scatter_rows_vec_kernel(const S* __restri
     constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte output chunk
     const int cpr = dim / EPC;                    // chunks per row
     const int items = rows_per_wg * cpr;
+    unsigned long long fresh = 0, dups = 0;   // rows this lane wrote / wrote over
     for (long long r0 = (long long)blockIdx.x * rows_per_wg; r0 < n; r0 += (long long)gridDim.x * rows_per_wg) {
         for (int w = threadIdx.x; w < items; w += blockDim.x) {
             const int lr = w / cpr, c = w - lr * cpr;
@@ -1231,10 +1238,18 @@ __global__ __launch_bounds__(256) void scatter_rows_vec_kernel(const S* __restri
             *(TV*)(rows + pos * dim + c * EPC) = o;
             if (c == 0) {
                 const int32_t old = atomicExch(&row_ids[pos], (int32_t)id);
-                if (old != ID_SENTINEL) atomicAdd(&meta[1], 1ull);
-                else atomicAdd(&meta[0], 1ull);
+                if (old != ID_SENTINEL) ++dups; else ++fresh;
             }
         }
+    }
+    // one add per wave instead of one per row on the same word
+    for (int d = 32; d > 0; d >>= 1) {
+        fresh += __shfl_down(fresh, d, 64);
+        dups += __shfl_down(dups, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (fresh) atomicAdd(&meta[0], fresh);
+        if (dups) atomicAdd(&meta[1], dups);
     }
 }
 
