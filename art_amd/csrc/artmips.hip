@@ -531,8 +531,14 @@ extern "C" int artmips_begin(artmips_t* h, int64_t n_rows_total) {
         s.next.row0 = lo;
         s.next.n_rows = hi - lo;
         if (s.next.n_rows > 0) {
-            const size_t rb = (size_t)s.next.n_rows * h->dim * elem_size(h->dtype);
+            // whole tiles: the scan's DMA reads 16-row tiles without a clamp (artmips_kernels.h)
+            const size_t row_bytes = (size_t)h->dim * elem_size(h->dtype);
+            const int64_t n_pad = (s.next.n_rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+            const size_t rb = (size_t)n_pad * row_bytes;
             hipError_t e = hipMalloc(&s.next.rows, rb);
+            if (e == hipSuccess && n_pad > s.next.n_rows)
+                e = hipMemsetAsync((char*)s.next.rows + (size_t)s.next.n_rows * row_bytes, 0,
+                                   (size_t)(n_pad - s.next.n_rows) * row_bytes, s.stream);
             if (e == hipSuccess) e = hipMalloc((void**)&s.next.ids, (size_t)s.next.n_rows * 4);
             if (e == hipSuccess) e = hipMalloc((void**)&s.next.meta, 32);
             // every id starts as ID_SENTINEL; artmips_finalize refuses a generation that still has one

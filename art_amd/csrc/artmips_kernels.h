@@ -17,7 +17,8 @@
 //   merge_kernel          per query: top-k of the union of per-shard top-k lists
 //
 // Layout facts the kernels rely on (checked on the host before every launch):
-//   rows: [n_rows, DIM] row-major, 16-byte aligned, DIM % 128 == 0
+//   rows: [n_rows rounded up to whole tiles, DIM] row-major, 16-byte aligned, DIM % 128 == 0; the rows
+//         past n_rows are zero
 //   a "tile" is 16 consecutive rows; a "piece" is 8 rows x 128 B = one LDS-DMA wave-instruction.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -294,22 +295,27 @@ __device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, PP + 1>(d);
     }
 }
-template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int AUX, int PPW, int NW, int C, typename V>
+// `pre` runs once per stage, behind the LDS read requests of the first two chunks and in front of the
+// wait for them: the place where the previous stage's filter epilogue costs least (its VALU work
+// overlaps the LDS latency, and the MFMA results it reads have settled while the wave sat at the
+// barrier).
+template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int AUX, int PPW, int NW, int C, typename V,
+          typename Pre>
 __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq)[KSTEPS],
-                                           const uint32_t (&base)[4], const MgDma& d) {
+                                           const uint32_t (&base)[4], const MgDma& d, const Pre& pre) {
     if constexpr (C < NCH) {
         if (!d.noread) {
             if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
-            if constexpr (C + 1 < NCH) {
-                mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
-                if (!d.nowait) mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
-            } else {
-                if (!d.nowait) mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
-            }
+            if constexpr (C + 1 < NCH) mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
+        }
+        if constexpr (C == 0) pre();
+        if (!d.noread && !d.nowait) {
+            if constexpr (C + 1 < NCH) mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
+            else mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
         }
         mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, 0>(d);
-        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, C + 1, V>(acc, af, bq, base, d);
+        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, C + 1, V, Pre>(acc, af, bq, base, d, pre);
     }
 }
 // MFMA results must not be read by ordinary VALU code before the pipeline has written them:
@@ -320,6 +326,18 @@ __device__ __forceinline__ void mg_settle(f32x4* acc) {
         if constexpr (J == 0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
         else asm volatile("" : "+v"(acc[J]));
         mg_settle<NQ, J + 1>(acc);
+    }
+}
+
+// the same in front of the deferred epilogue: the wave has since passed a counted wait, the barrier,
+// the loop head and four LDS read requests (well over the 11 wait states an 8-pass MFMA needs before
+// VALU may read its result); the pad is margin against the compiler moving that code
+template <int NQ, int J>
+__device__ __forceinline__ void mg_settle_short(f32x4* acc) {
+    if constexpr (J < NQ) {
+        if constexpr (J == 0) asm volatile("s_nop 7" : "+v"(acc[0]));
+        else asm volatile("" : "+v"(acc[J]));
+        mg_settle_short<NQ, J + 1>(acc);
     }
 }
 
@@ -433,7 +451,6 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     const T* __restrict__ rows = (const T*)a.rows;
     const long long n_rows = a.n_rows;
-    const long long last_row = n_rows - 1;
 
     // ---- query operand: KSTEPS fragments of 8 elements, resident in registers for the whole launch
     V bq[NQ][KSTEPS];
@@ -469,30 +486,16 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         lane_off[pp] = (uint32_t)(trow * ROWB + (((pos - trow * CPR) ^ (trow & 15)) * 16));
     }
 
-    auto issue_stage = [&](long long it, int slot) {
+    // The shard's row buffer is allocated in whole tiles (artmips_begin pads it with zero rows), so a
+    // DMA never needs a per-lane clamp: uniform tile base + per-lane constant.  Rows past n_rows are
+    // scored like any other and dropped by the `row < n_rows` test of the filter.
+    auto issue_stage = [&](long long it, int slot) __attribute__((always_inline)) {
         long long wk = b + it * grid;
         if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
-        const long long row0 = wk * stride * TILE_ROWS;
-        char* slot_base = smem + slot * STAGE_BYTES;
-        if (row0 + TILE_ROWS <= n_rows) {
-            // whole tile in range (all but the last tile): uniform base + per-lane constant
-            const char* tile = (const char*)rows + row0 * ROWB;
-            const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
+        const char* tile = (const char*)rows + wk * stride * TILE_ROWS * ROWB;
+        const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
 #pragma unroll
-            for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
-            return;
-        }
-#pragma unroll
-        for (int pp = 0; pp < PPW; ++pp) {
-            const int p = w * PPW + pp;
-            const int pos = p * 64 + lane;         // 16-byte slot of the stage this lane fills
-            const int trow = pos / CPR;            // row of the tile the slot belongs to
-            const int chunk = (pos - trow * CPR) ^ (trow & 15);
-            long long row = row0 + trow;
-            if (row > last_row) row = last_row;    // short last tile: re-read the last row
-            const T* src = rows + row * DIM + chunk * EPC;
-            glds16<AUX>(src, slot_base + p * 1024);
-        }
+        for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
     };
 
     static_assert(TOPT == 1 || MODE == MODE_GROUPMAX, "TOPT belongs to pass 0");
@@ -516,9 +519,53 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     constexpr int SLOTS = STAGING_BYTES / (NT * NQ * 8);
     static_assert(SLOTS >= 1, "staging area too small");
     int2* const stg = (int2*)(smem + NSTAGE * STAGE_BYTES);   // [NQ][SLOTS][NT]
-    auto flush = [&](int j, int first, int last) {  // copy staged entries [first, last) to HBM
+    auto flush = [&](int j, int first, int last) __attribute__((always_inline)) {  // copy staged entries [first, last) to HBM
         for (int e = first; e < last; ++e)
             if (e < a.cap) my_list[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * NT + tid];
+    };
+
+    // Filter (or pass-0 maxima) of one finished stage: acc[j][i] = score(row = tile*16 + g*4 + i,
+    // query = j*QG + w*16 + r)
+    f32x4 acc[NQ];
+    auto epilogue = [&](long long it_e) __attribute__((always_inline)) {
+        const long long row_base = (b + it_e * grid) * stride * TILE_ROWS + g * 4;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (ablate & 16) {
+                asm volatile("" ::"v"(acc[j]));   // diagnostic build: no filter, scores kept live
+            } else if (MODE == MODE_FILTER) {
+                const float m = fmaxf(fmaxf(acc[j][0], acc[j][1]), fmaxf(acc[j][2], acc[j][3]));
+                if (__builtin_amdgcn_ballot_w64(m >= thr[j]) != 0ull) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long row = row_base + i;
+                        if (acc[j][i] >= thr[j] && row < n_rows) {
+                            if (STG) {
+                                const int slot_e = cnt[j] % SLOTS;
+                                if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
+                                stg[(j * SLOTS + slot_e) * NT + tid] = make_int2(__float_as_int(acc[j][i]), (int)row);
+                            } else if (cnt[j] < a.cap) {
+                                my_list[j * list_stride + cnt[j]] = make_int2(__float_as_int(acc[j][i]), (int)row);
+                            }
+                            ++cnt[j];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long row = row_base + i;
+                    // insertion into the lane's descending top-TOPT (NaN never enters)
+                    float x = (row < n_rows) ? acc[j][i] : -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < TOPT; ++t) {
+                        const float hi = fmaxf(gm[j][t], x);
+                        x = fminf(gm[j][t], x);
+                        gm[j][t] = hi;
+                    }
+                }
+            }
+        }
     };
 
     if (n_it > 0) {
@@ -550,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 long long wk = b + (it + NSTAGE - 1) * grid;
                 if (wk > last_work) wk = last_work;
                 const long long row0 = wk * stride * TILE_ROWS;
-                dma.on = wave_active && (row0 + TILE_ROWS <= n_rows) && !(ablate & 1);
+                dma.on = wave_active && !(ablate & 1);
                 dma.tile = (const char*)rows + row0 * ROWB;
                 dma.lane_off = lane_off;
                 dma.dst0 = lds_base + (uint32_t)(fill_slot * STAGE_BYTES + w * PPW * 1024);
@@ -561,7 +608,6 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
             if (wave_active) {
                 const char* sb = smem + slot * STAGE_BYTES;
-                f32x4 acc[NQ];
                 if constexpr (NQ == 1) {
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -587,58 +633,30 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                         __builtin_amdgcn_sched_group_barrier(0x100, CHB, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, CHB * NQ * MPF, 0);
                     }
+                    epilogue(it);
                 } else {
-                    // chunks of CH k-steps, row fragments double-buffered in registers
+                    // chunks of CH k-steps, row fragments double-buffered in registers; the filter of
+                    // the PREVIOUS stage runs inside, behind the first LDS read requests (mg_compute)
                     V af[2][CH];
                     uint32_t base[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) base[m] = lds_base + (uint32_t)(slot * STAGE_BYTES + rd_off[m]);
-                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma);
-                    mg_settle<NQ, 0>(acc);
-                }
-                // acc[j][i] = score(row = tile*16 + g*4 + i, query = j*64 + w*16 + r)
-                const long long row_base = (b + it * grid) * stride * TILE_ROWS + g * 4;
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    if (ablate & 16) {
-                        asm volatile("" ::"v"(acc[j]));   // diagnostic build: no filter, scores kept live
-                    } else if (MODE == MODE_FILTER) {
-                        const float m = fmaxf(fmaxf(acc[j][0], acc[j][1]), fmaxf(acc[j][2], acc[j][3]));
-                        if (__builtin_amdgcn_ballot_w64(m >= thr[j]) != 0ull) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const long long row = row_base + i;
-                                if (acc[j][i] >= thr[j] && row < n_rows) {
-                                    if (STG) {
-                                        const int slot_e = cnt[j] % SLOTS;
-                                        if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
-                                        stg[(j * SLOTS + slot_e) * NT + tid] =
-                                            make_int2(__float_as_int(acc[j][i]), (int)row);
-                                    } else if (cnt[j] < a.cap) {
-                                        my_list[j * list_stride + cnt[j]] =
-                                            make_int2(__float_as_int(acc[j][i]), (int)row);
-                                    }
-                                    ++cnt[j];
-                                }
-                            }
+                    auto pre = [&]() __attribute__((always_inline)) {
+                        if (it > 0) {
+                            mg_settle_short<NQ, 0>(acc);
+                            epilogue(it - 1);
                         }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const long long row = row_base + i;
-                            // insertion into the lane's descending top-TOPT (NaN never enters)
-                            float x = (row < n_rows) ? acc[j][i] : -INFINITY;
-#pragma unroll
-                            for (int t = 0; t < TOPT; ++t) {
-                                const float hi = fmaxf(gm[j][t], x);
-                                x = fminf(gm[j][t], x);
-                                gm[j][t] = hi;
-                            }
-                        }
-                    }
+                    };
+                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma, pre);
                 }
             }
             slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+        }
+        if constexpr (NQ > 1) {
+            if (wave_active) {   // the last stage's filter (every other stage's ran inside the next one)
+                mg_settle<NQ, 0>(acc);
+                epilogue(n_it - 1);
+            }
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
         wait_vmcnt<0>();
