@@ -526,8 +526,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     // Filter (or pass-0 maxima) of one finished stage: acc[j][i] = score(row = tile*16 + g*4 + i,
     // query = j*QG + w*16 + r)
-    f32x4 acc[NQ];
-    auto epilogue = [&](long long it_e) __attribute__((always_inline)) {
+    f32x4 acc[NQ];   // multi-group path: lives across iterations (its filter runs one stage late)
+    auto epilogue = [&](long long it_e, f32x4* acc) __attribute__((always_inline)) {
         const long long row_base = (b + it_e * grid) * stride * TILE_ROWS + g * 4;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             if (wave_active) {
                 const char* sb = smem + slot * STAGE_BYTES;
                 if constexpr (NQ == 1) {
+                    f32x4 acc[NQ];
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     // the row fragments of a chunk are all requested before its first MFMA, so the LDS
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                         __builtin_amdgcn_sched_group_barrier(0x100, CHB, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, CHB * NQ * MPF, 0);
                     }
-                    epilogue(it);
+                    epilogue(it, acc);
                 } else {
                     // chunks of CH k-steps, row fragments double-buffered in registers; the filter of
                     // the PREVIOUS stage runs inside, behind the first LDS read requests (mg_compute)
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                     auto pre = [&]() __attribute__((always_inline)) {
                         if (it > 0) {
                             mg_settle_short<NQ, 0>(acc);
-                            epilogue(it - 1);
+                            epilogue(it - 1, acc);
                         }
                     };
                     mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma, pre);
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         if constexpr (NQ > 1) {
             if (wave_active) {   // the last stage's filter (every other stage's ran inside the next one)
                 mg_settle<NQ, 0>(acc);
-                epilogue(n_it - 1);
+                epilogue(n_it - 1, acc);
             }
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
