@@ -297,3 +297,32 @@ def test_spmd_pipelined_nccl_world1(gu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- against the outputs of the reference's OWN search_mips_index (tests/golden/fx_ref_search.npz:
+# art_index.py:200-304 executed in the build container with device placement redirected to the CPU)
+@pytest.mark.parametrize("fam", ["int", "rnd"])
+def test_engine_matches_the_reference_output(gu, golden_dir, fam):
+    import re
+    from tests.ref_search_check import check_against_reference
+    fx = np.load(os.path.join(golden_dir, "fx_ref_search.npz"))
+    rows, queries, ids = fx[fam + "_rows"], fx[fam + "_queries"], fx[fam + "_ids"]
+    full = orc.exact_scores(queries.astype(np.float64), rows.astype(np.float64))
+    engines = {}
+    groups = 0
+    for key in fx.files:
+        m = re.match(fam + r"_g(\d)_k(\d+)_dist$", key)
+        if not m:
+            continue
+        g, k = int(m.group(1)), int(m.group(2))
+        if g not in engines:   # the reference's G GPUs = G row shards here, split by the same torch.chunk rule
+            engines[g] = gu.build_engine(rows, ids, devices=[0] * g)
+        s, i = gu.search_np(engines[g], queries, k)
+        groups += check_against_reference(fx[key], fx[key.replace("_dist", "_idx")], s, i, full, ids)
+        # the caller-facing fp16 distances are the reference's, bit for bit
+        q = torch.from_numpy(queries).cuda()
+        d16, _ = engines[g].search(q, k)   # default score dtype: float16 (art_model.py:358)
+        assert np.array_equal(d16.cpu().numpy(), fx[key])
+    assert groups > 100
+    for e in engines.values():
+        e.close()
