@@ -178,6 +178,12 @@ struct ScanArgs {
     int gang;
     int q_tile;           // queries per workgroup (64 * NQ * NW / 4)
     long long lists_member_stride;  // int2 entries between the list regions of two members
+    // Two-part FILTER scan (large k): part A visits every 4th tile (tile_stride = 4), the k-th best score
+    // among its survivors then raises thr, and part B visits the other tiles (tile_skip: work index w ->
+    // tile (w / 3) * 4 + w % 3 + 1) and appends to the same lists (counts_continue: the lanes' counters
+    // start at what part A left in `counts`; direct list writes only, STG == 0).
+    int tile_skip;
+    int counts_continue;
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE; results are
                           // then meaningless): 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
 };
@@ -475,6 +481,14 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const long long stride = a.tile_stride;
     const long long n_it = (b < n_work) ? (n_work - b + grid - 1) / grid : 0;
     const long long last_work = n_work - 1;
+    // work index -> tile (see ScanArgs::tile_skip; tile counts fit 32 bits: n_rows < 2^31)
+    auto tile_of = [&](long long wk) __attribute__((always_inline)) -> long long {
+        if (a.tile_skip) {
+            const uint32_t w32 = (uint32_t)wk;
+            return (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
+        }
+        return wk * stride;
+    };
 
     // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
     // (DMA side): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
@@ -492,7 +506,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     auto issue_stage = [&](long long it, int slot) __attribute__((always_inline)) {
         long long wk = b + it * grid;
         if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
-        const char* tile = (const char*)rows + wk * stride * TILE_ROWS * ROWB;
+        const long long row0 = tile_of(wk) * TILE_ROWS;
+        const char* tile = (const char*)rows + row0 * ROWB;
         const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
@@ -504,6 +519,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         cnt[j] = 0;
+        if (MODE == MODE_FILTER && !STG && a.counts_continue)
+            cnt[j] = a.counts[(per_query_off + (size_t)(j * QG + w * 16 + r)) * (size_t)(grid * 4) + (size_t)(b * 4 + g)];
 #pragma unroll
         for (int t = 0; t < TOPT; ++t) gm[j][t] = -INFINITY;
     }
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // query = j*QG + w*16 + r)
     f32x4 acc[NQ];   // multi-group path: lives across iterations (its filter runs one stage late)
     auto epilogue = [&](long long it_e, f32x4* acc) __attribute__((always_inline)) {
-        const long long row_base = (b + it_e * grid) * stride * TILE_ROWS + g * 4;
+        const long long row_base = tile_of(b + it_e * grid) * TILE_ROWS + g * 4;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (ablate & 16) {
@@ -596,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             if constexpr (ASM_PATH && INLINE_DMA) {
                 long long wk = b + (it + NSTAGE - 1) * grid;
                 if (wk > last_work) wk = last_work;
-                const long long row0 = wk * stride * TILE_ROWS;
+                const long long row0 = tile_of(wk) * TILE_ROWS;
                 dma.on = wave_active && !(ablate & 1);
                 dma.tile = (const char*)rows + row0 * ROWB;
                 dma.lane_off = lane_off;
@@ -967,6 +984,9 @@ struct SelectArgs {
                             // then belongs to member q / q_member, whose lists start
                             // lists_member_stride entries further on
     long long lists_member_stride;
+    float* refine_thr;      // non-NULL: refine mode.  Nothing is selected or written out; instead
+                            // refine_thr[q] is raised to the k-th best score among the candidates kept so
+                            // far (scores of k distinct rows: still a lower bound of the final k-th best)
     const int32_t* ids;     // [n_rows] passage id of each local row
     u64* keys_ws;           // [q_tile][keys_stride] global key scratch for M > SORT_MAX
     long long keys_stride;
@@ -1025,6 +1045,28 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         }
     }
     if (tid == 0) loff[L] = M;
+    if (a.refine_thr != nullptr) {
+        // refine mode: M and every branch below are uniform over the workgroup
+        if (M < a.k || M > SCORE_MAX) return;   // too few rows seen for a bound / too many for LDS: keep thr
+        __syncthreads();
+        const int cpt_r = (M + nt - 1) / nt;
+        const int eb = tid * cpt_r, ee = (eb + cpt_r < M) ? eb + cpt_r : M;
+        if (eb < ee) {
+            int lo = 0, hi = L;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (loff[mid] <= eb) lo = mid; else hi = mid;
+            }
+            for (int e = eb; e < ee; ++e) {
+                while (loff[lo + 1] <= e) ++lo;
+                big[e] = f2ord(__int_as_float(lists[list_of(lo) * (size_t)a.cap + (e - loff[lo])].x));
+            }
+        }
+        __syncthreads();
+        const uint32_t kth = radix_kth<uint32_t>(big, M, a.k, hist, ctl);
+        if (tid == 0) a.refine_thr[q] = fmaxf(a.refine_thr[q], ord2f(kth));
+        return;
+    }
     if (ovf) atomicOr(a.status, 1);
     if (tid == 0) atomicAdd(a.cand_total, (unsigned long long)M);
     __syncthreads();

@@ -69,7 +69,9 @@ def test_k2048_integer_ties_with_pass0(gu):
     (70000, 800, 32, "f16"),      # gang of 4 whose fourth member holds 32 queries
     (50000, 600, 1000, "bf16"),   # gang of 2 + 88 queries as a 4 x 2 launch, direct list writes
     (40000, 2100, 10, "f16"),     # one gang of 8 (2,048 queries) + 52 queries
-    (60000, 1900, 1000, "bf16"),  # gang of 8 whose last member holds 108 queries, k = 1000
+    (60000, 1900, 1000, "bf16"),  # gang of 8 whose last member holds 108 queries, k = 1000 (two-part scan)
+    (70000, 1100, 500, "f16"),    # gang of 4 + 76 queries; two-part scan with threshold refinement
+    (300000, 300, 1000, "f16"),   # 8 x 2 without a gang, two-part scan, + 44 queries
     (36000, 450, 50, "f16"),      # gang of 2 with 194 queries in the second member, small shard
 ])
 def test_gang_launches_vs_oracle(gu, n, q, k, storage):
@@ -87,7 +89,7 @@ def test_gang_launches_vs_oracle(gu, n, q, k, storage):
     # batch position and launch shape must not matter: the same queries alone give the same bits
     qd = torch.from_numpy(queries).to(tdt).cuda()
     s_all, i_all = eng.search(qd, k, score_dtype=torch.float32)
-    for a, b in ((0, 64), (q - 40, q), (300, 364)):
+    for a, b in ((0, 64), (q - 40, q), (q // 2, q // 2 + 64)):
         s1, i1 = eng.search(qd[a:b], k, score_dtype=torch.float32)
         assert torch.equal(i1, i_all[a:b]) and torch.equal(s1, s_all[a:b])
     eng.close()
