@@ -791,7 +791,8 @@ struct Plan {
     int nw;               // waves per scan workgroup (4 or 8); a column group is 16*nw queries
     bool stage_lds;       // stage survivors in LDS (few per lane) instead of storing them directly
     int topt;             // sample values each pass-0 lane keeps per query (1, or 4 for large k)
-    bool refine;          // two-part FILTER scan with a threshold refinement in between (large k)
+    int refine;           // 0, or the period P (4 or 8) of the two-part FILTER scan: every P-th tile,
+                          // a threshold refinement, then the other tiles (large k)
     int gang;             // workgroups that walk the same tiles with different query blocks (1, 2, 4, 8);
                           // grid and grid0 are LOGICAL (per gang member): launches use grid * gang
 };
@@ -838,15 +839,30 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
         std::sqrt(0.45 * row_scale * (double)p.n_tiles / ((double)k * groups_per_wave)));
     sample_div = std::min<long long>(128, std::max<long long>(16, sample_div));
     if (const int sd = diag_int("ARTMIPS_SAMPLE_DIV", 0)) sample_div = std::max(4, sd);
-    long long sample = std::max<long long>(grid0, p.n_tiles / sample_div);
-    p.pass0 = (grid0 * per_wg >= k) && (sample * 4 <= p.n_tiles);
-    if (p.pass0) {
+    const int staging_slots = STAGING_BYTES / (nw * 64 * nq * 8);
+    // Fills in the pass-0 part of the plan for a sample of n_tiles / sd tiles; `survivors(kept)` is the
+    // expected number of candidates per query given the tiles per query-sample `kept` = n_tiles / n_sample
+    auto with_sample = [&](long long sd, int period) {
+        long long sample = std::max<long long>(grid0, p.n_tiles / sd);
+        p.pass0 = (grid0 * per_wg >= k) && (sample * 4 <= p.n_tiles);
+        p.refine = 0;
+        if (!p.pass0) {
+            p.stage_lds = false;
+            p.grid0 = 0;
+            p.n_sample = 0;
+            p.sample_stride = 1;
+            p.cap = (int)cap_max;  // threshold is -inf: every row is a candidate
+            return;
+        }
         const long long t0 = std::max<long long>(1, sample / grid0);
         p.grid0 = (int)grid0;
         p.n_sample = grid0 * t0;
         p.sample_stride = p.n_tiles / p.n_sample;
-        // expected survivors per query: k * n_tiles / n_sample (loose by the group approximation)
-        const double expect = (double)k * (double)p.n_tiles / (double)p.n_sample;
+        // expected survivors per query: k * n_tiles / n_sample (loose by the group approximation) in
+        // one part; in two parts the first 1/P of the tiles keeps that rate and the rest is filtered
+        // at the k-th best of the first part, i.e. at rank k * P of the shard
+        const double rate = (double)k * (double)p.n_tiles / (double)p.n_sample;
+        const double expect = period ? rate / period + (double)k * (period - 1) : rate;
         const double per_list = expect / ((double)p.grid * 4.0);
         long long cap = round_up_pow2((long long)std::ceil(per_list * 8.0) + 16);
         cap *= cap_boost;
@@ -854,29 +870,31 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
         // LDS staging holds 8/nq survivors per lane and column group; it pays while a lane flushes
         // at most a few times per launch (profiles/r01_j_lds_staging_ab.txt)
         // (8 waves x 2 groups has no registers left for the staging bookkeeping: it would spill in the loop)
-    p.stage_lds = !(nw == 8 && nq == 2) && per_list <= 4.0 * (STAGING_BYTES / (nw * 64 * nq * 8));
-    } else {
-        p.stage_lds = false;
-        p.grid0 = 0;
-        p.n_sample = 0;
-        p.sample_stride = 1;
-        p.cap = (int)cap_max;  // threshold is -inf: every row is a candidate
+        p.stage_lds = !(nw == 8 && nq == 2) && per_list <= 4.0 * staging_slots;
+        p.refine = period;
+    };
+    // Large k: pass 0 at the fitted sample_div (16 where the scan is MFMA-bound) is 1/16 of the scan's
+    // own cost and still leaves k * 16 survivors per query.  The FILTER scan therefore runs in two
+    // parts: every P-th tile first, then the k-th best score among THOSE survivors (rank k * P of the
+    // whole shard) replaces the threshold for the other tiles.  That makes a 4 x coarser sample
+    // affordable: with P = 8 and sample_div = 64 the two parts keep 8k + 7k candidates per query at
+    // top-1000 (16k before) and pass 0 shrinks from 6.3 % to 1.6 % of the scan.  Still exact: the new
+    // threshold is the score of k distinct rows already seen.  Needs direct list writes (the LDS staging
+    // has no continuation across launches) and enough tiles for both parts to fill the grid.
+    int period = 8;
+    if (const int r = diag_int("ARTMIPS_REFINE", -1); r >= 0) period = (r == 4 || r == 8) ? r : 0;
+    bool two_part = false;
+    if (period && k > 128 && p.n_tiles >= 64ll * p.grid) {
+        // (part A's survivors, k * sd_r / P per query, must fit the refinement's LDS: SCORE_MAX)
+        long long sd_r = std::min<long long>(std::min<long long>(128, sample_div * 4), 20000ll * period / k);
+        if (const int sd = diag_int("ARTMIPS_SAMPLE_DIV", 0)) sd_r = std::max(4, sd);
+        if (sd_r >= sample_div) {
+            with_sample(sd_r, period);
+            two_part = p.pass0 && !p.stage_lds;
+        }
     }
+    if (!two_part) with_sample(sample_div, 0);
     if (p.cap < 1) p.cap = 1;
-    // Large k leaves k * sample_div survivors per query (16k at top-1000).  Where that is more than
-    // one survivor per ~1,000 rows and query, a wave finds one in a large share of its tiles and the
-    // filter's slow path (exec-masked list writes) shows: the FILTER scan then runs in two parts --
-    // every 4th tile first, then the k-th best score among THOSE survivors (rank ~4k of the whole
-    // shard instead of ~16k) replaces the threshold for the other three quarters: 7k survivors
-    // instead of 16k.  Still exact: the new threshold is the score of k distinct rows already seen.
-    // Measured, 2,048 x top-1000: 8.8M rows 28.85 -> 28.15 ms per call (-2.4 %), 21M rows 64.3 -> 64.6
-    // (nothing to gain: the density is 0.76 per 1,000 rows), hence the density condition.
-    p.refine = false;
-    if (p.pass0 && !p.stage_lds && k > 128 && p.n_tiles >= 64ll * p.grid) {
-        const double expect = (double)k * (double)p.n_tiles / (double)p.n_sample;
-        p.refine = expect >= 1e-3 * (double)n_rows;
-    }
-    if (const int r = diag_int("ARTMIPS_REFINE", -1); r >= 0) p.refine = p.refine && r != 0;
     return p;
 }
 
@@ -1010,9 +1028,10 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     }
     int rc = 0;
     if (p.refine) {
-        // part A: tiles 0, 4, 8, ...
-        a.n_work = (p.n_tiles + 3) / 4;
-        a.tile_stride = 4;
+        // part A: tiles 0, P, 2P, ...
+        const long long part_a = (p.n_tiles + p.refine - 1) / p.refine;
+        a.n_work = part_a;
+        a.tile_stride = p.refine;
         if ((rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid * p.gang, st))) return rc;
         DEBUG_STEP(st, "scan<FILTER> part A grid=%d tiles=%lld", p.grid * p.gang, a.n_work);
         // thr[q] <- max(thr[q], k-th best score among the survivors of part A)
@@ -1022,9 +1041,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "refine grid=%d", q_count);
         // part B: the other tiles, appended to the same lists
-        a.n_work = p.n_tiles - (p.n_tiles + 3) / 4;
+        a.n_work = p.n_tiles - part_a;
         a.tile_stride = 1;
-        a.tile_skip = 1;
+        a.tile_skip = p.refine;
         a.counts_continue = 1;
     } else {
         a.n_work = p.n_tiles;

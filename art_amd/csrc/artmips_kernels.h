@@ -178,10 +178,11 @@ struct ScanArgs {
     int gang;
     int q_tile;           // queries per workgroup (64 * NQ * NW / 4)
     long long lists_member_stride;  // int2 entries between the list regions of two members
-    // Two-part FILTER scan (large k): part A visits every 4th tile (tile_stride = 4), the k-th best score
-    // among its survivors then raises thr, and part B visits the other tiles (tile_skip: work index w ->
-    // tile (w / 3) * 4 + w % 3 + 1) and appends to the same lists (counts_continue: the lanes' counters
-    // start at what part A left in `counts`; direct list writes only, STG == 0).
+    // Two-part FILTER scan (large k): part A visits every P-th tile (tile_stride = P; P = 4 or 8), the
+    // k-th best score among its survivors then raises thr, and part B visits the other tiles (tile_skip
+    // = P: work index w -> tile (w / (P-1)) * P + w % (P-1) + 1) and appends to the same lists
+    // (counts_continue: the lanes' counters start at what part A left in `counts`; direct list writes
+    // only, STG == 0).
     int tile_skip;
     int counts_continue;
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE; results are
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     auto tile_of = [&](long long wk) __attribute__((always_inline)) -> long long {
         if (a.tile_skip) {
             const uint32_t w32 = (uint32_t)wk;
-            return (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
+            return (a.tile_skip == 8) ? (long long)((w32 / 7u) * 8u + w32 % 7u + 1u)
+                                      : (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
         }
         return wk * stride;
     };

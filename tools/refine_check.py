@@ -1,11 +1,40 @@
-import os, sys, torch
-R=os.environ["GRAFT_REPO_ROOT"]; sys.path.insert(0,R)
-os.environ["ARTMIPS_LIBRARY"]=R+"/art_amd/lib/libartmips_diag.so"
-import bench
-from art_amd.engine import MipsEngine
-eng=MipsEngine(768, torch.float16,[0]); bench.build_shard(eng,0,int(sys.argv[1]),1234,torch.float16)
-q=torch.randn((2048,768),device="cuda").half()
-for r in ("0","1"):
-    os.environ["ARTMIPS_REFINE"]=r
-    for _ in range(2): eng.search(q,1000)
-    i=eng.info(); print("refine",r,"cand/query",i["last_candidates"]/2048,"scan ms",i["last_scan_ms"],"total",i["last_total_ms"])
+#!/usr/bin/env python
+"""Two-part FILTER scan A/B in the diagnostic build: 2,048 queries x top-k over a synthetic shard with
+ARTMIPS_REFINE = 0 (one part, fitted sample), 4 and 8 (every 4th / 8th tile first, 4 x coarser sample).
+Prints candidates per query, the FILTER scan time and the whole pipeline time (HIP events) and checks
+that the three settings return identical ids.  usage: refine_check.py ROWS [K] [QUERIES] [REFINE[:SAMPLE_DIV],...]"""
+import os
+import sys
+
+import torch
+
+R = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+os.environ["ARTMIPS_LIBRARY"] = R + "/art_amd/lib/libartmips_diag.so"
+import bench  # noqa: E402
+from art_amd.engine import MipsEngine  # noqa: E402
+
+rows = int(sys.argv[1])
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+eng = MipsEngine(768, torch.float16, [0])
+bench.build_shard(eng, 0, rows, 1234, torch.float16)
+q = torch.randn((nq, 768), device="cuda").half()
+ref = None
+variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["0", "4", "8", "0", "8"]
+for v in variants:   # REFINE or REFINE:SAMPLE_DIV
+    r, _, sd = v.partition(":")
+    os.environ["ARTMIPS_REFINE"] = r
+    os.environ.pop("ARTMIPS_SAMPLE_DIV", None)
+    if sd:
+        os.environ["ARTMIPS_SAMPLE_DIV"] = sd
+    for _ in range(2):
+        s, ids = eng.search(q, k)
+    i = eng.info()
+    same = True if ref is None else bool(torch.equal(ids, ref))
+    if ref is None:
+        ref = ids.clone()
+    print("refine", v, "cand/query %.0f" % (i["last_candidates"] / nq), "scan ms %.3f" % i["last_scan_ms"],
+          "pipeline ms %.3f" % i["last_total_ms"], "ids identical", same, flush=True)
+    if not same:
+        sys.exit(1)
