@@ -96,7 +96,9 @@ struct Shard {
     std::vector<hipEvent_t> ev_scan;                   // pairs around each FILTER scan
     // workspace
     DevBuf qpad, thr, gmax, counts, lists, keys, status, qin, loc_scores, loc_ids, loc_packed;
-    int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints)
+    int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints), written by the
+                                 // last select launch of a search itself (SelectArgs::publish)
+    int* status_host_dev = nullptr;  // the same words as the device sees them
 };
 
 // Device scratch of one shard pipeline: pointers into the shard's own buffers (grown on demand), or
@@ -421,7 +423,8 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
             hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreate(&s.ev_t0) != hipSuccess || hipEventCreate(&s.ev_t1) != hipSuccess ||
-            hipHostMalloc((void**)&s.status_host, 64, hipHostMallocDefault) != hipSuccess) {
+            hipHostMalloc((void**)&s.status_host, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&s.status_host_dev, s.status_host, 0) != hipSuccess) {
             artmips_destroy(h);
             return fail(ARTMIPS_ERR_HIP, "stream/event creation failed on device %d", s.dev);
         }
@@ -928,7 +931,7 @@ static void launch_pack(const void* q, int q_dtype, int q_count, int q_tile, int
 static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p, const void* q_tile,
                         int q_dtype, int q_count, int k, void* out_scores, int score_dtype,
                         int32_t* out_ids, long long out_row0, hipStream_t st, int tile_index, bool timed,
-                        int* status) {
+                        int* status, bool publish) {
     const Generation& gen = s.live;
     const int qm = p.nq * p.nw * 16;   // queries per workgroup
     const int qt = qm * p.gang;        // queries of this launch (gang members hold qm each)
@@ -1016,6 +1019,10 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     sa.out_row0 = out_row0;
     sa.status = status;
     sa.cand_total = (unsigned long long*)(status + 2);
+    sa.stop_after = diag_int("ARTMIPS_SELECT_STOP", 0);   // diagnostic build only
+    // last launch of a search that wants its status on the host: the select publishes it itself
+    sa.publish = publish ? s.status_host_dev : nullptr;
+    sa.done_counter = ws.status + 8;   // word 8 of the shard's own status block (zeroed when allocated)
 
     a.ablate = diag_int("ARTMIPS_ABLATE", 0);  // diagnostic build only: results are then meaningless
     if (timed) {
@@ -1037,6 +1044,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         // thr[q] <- max(thr[q], k-th best score among the survivors of part A)
         SelectArgs ra = sa;
         ra.refine_thr = ws.thr;
+        ra.publish = nullptr;
         hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(SEL_THREADS), 0, st, ra);
         HIP_TRY(hipGetLastError());
         DEBUG_STEP(st, "refine grid=%d", q_count);
@@ -1204,7 +1212,10 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     } else {
         if ((rc = ensure(s.qpad, sz_qpad))) return rc;
         if ((rc = ensure(s.thr, sz_thr))) return rc;
-        if ((rc = ensure(s.status, 64))) return rc;
+        if (!s.status.p) {
+            if ((rc = ensure(s.status, 64))) return rc;
+            HIP_TRY(hipMemset(s.status.p, 0, 64));   // word 8 is select_kernel's done counter
+        }
         if (sz_gmax && (rc = ensure(s.gmax, sz_gmax))) return rc;
         if ((rc = ensure(s.counts, sz_counts))) return rc;
         if ((rc = ensure(s.lists, sz_lists))) return rc;
@@ -1227,12 +1238,13 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     const int total_launches = n_launches + (int)overflow_launches.size();
     for (int li = 0; li < total_launches; ++li, ++c.n_tiles_q) {
         const Launch& l = li < 64 ? launches[li] : overflow_launches[li - 64];
+        const bool publish = c.host_status && !c.static_scratch && li == total_launches - 1;
         rc = enqueue_tile(h, s, ws, l.plan, (const char*)c.q_dev + (size_t)l.q0 * q_row_bytes, c.q_dtype, l.qc,
-                          c.k, c.out_scores, c.score_dtype, c.out_ids, l.q0, c.st, c.n_tiles_q, timed, status);
+                          c.k, c.out_scores, c.score_dtype, c.out_ids, l.q0, c.st, c.n_tiles_q, timed, status,
+                          publish);
         if (rc) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(s.ev_t1, c.st));
-    if (c.host_status) HIP_TRY(hipMemcpyAsync(s.status_host, status, 16, hipMemcpyDeviceToHost, c.st));
     c.t_enq = std::chrono::steady_clock::now();
     return 0;
 }

@@ -812,6 +812,47 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
     return off;
 }
 
+// Sort one 32-bit value per lane across the wave, descending, in registers (bitonic network over
+// __shfl_xor: 21 exchange steps, no LDS, no barrier).  Lane i returns the (i+1)-th largest.
+__device__ __forceinline__ uint32_t wave_sort_desc(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t o = __shfl_xor(v, stride, 64);
+            const bool desc = ((lane & size) == 0);      // direction of this lane's block
+            const bool lower = ((lane & stride) == 0);   // lower lane of the pair
+            v = (lower == desc) ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+
+// Small-k selection without a radix pass.  `mine` is the largest ordered score among the values this
+// thread looked at (0 if it saw none); the values of different threads belong to different rows.  Each
+// wave sorts its 64 thread maxima in registers and offers its r-th largest, r = ceil(k / waves); the
+// minimum B of the offers is a lower bound of the k-th best score of ALL values: every wave has r
+// threads whose maximum is >= its offer >= B, which makes waves * r >= k distinct rows at or above B.
+// On random data about 1.3-1.5 k values survive `>= B`, few enough to rank by counting.  B == 0 (a
+// wave with fewer than r threads that saw anything) keeps everything, which is still correct.
+// wsum: 32 words of LDS.  Needs ceil(k / waves) <= 64.  All threads return the same B.
+__device__ __forceinline__ uint32_t wave_offer_bound(uint32_t mine, int k, uint32_t* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const int r = (k + nw - 1) / nw;
+    const uint32_t sorted = wave_sort_desc(mine);
+    const uint32_t offer = __shfl(sorted, r - 1, 64);
+    if (lane == 0) wsum[wv] = offer;
+    __syncthreads();
+    uint32_t b = 0xffffffffu;
+    for (int w = 0; w < nw; ++w) b = wsum[w] < b ? wsum[w] : b;
+    __syncthreads();
+    return b;
+}
+
+constexpr int RANK_MAX = 512;   // survivors ranked by counting (RANK_MAX^2 / threads LDS reads per thread)
+
 // ---------------------------------------------------------------------------------------------
 // kth_kernel (pass 0): tau[q] = k-th largest of the per-lane sample values (the lane's maximum, or
 // its four best) that belong to query q.  Each value is the score of a distinct row, so k of them >= tau proves that the k-th best
@@ -840,8 +881,45 @@ __global__ __launch_bounds__(SEL_THREADS) void kth_kernel(const float* __restric
         if (tid == 0) thr[q] = -INFINITY;
         return;
     }
-    for (int i = tid; i < G; i += blockDim.x) vals[i] = f2ord(gmax[(size_t)q * G + i]);
+    uint32_t mine = 0;
+    for (int i = tid; i < G; i += blockDim.x) {
+        const uint32_t v = f2ord(gmax[(size_t)q * G + i]);
+        vals[i] = v;
+        mine = v > mine ? v : mine;
+    }
     __syncthreads();
+    if (k <= 128 && (k + (int)(blockDim.x >> 6) - 1) / (int)(blockDim.x >> 6) <= 64) {
+        // small k: bound from the waves' sorted thread maxima, then the exact k-th largest of the few
+        // values at or above it, by counting (no radix passes)
+        __shared__ uint32_t surv[RANK_MAX];
+        __shared__ uint32_t wofs[32];
+        const uint32_t bound = wave_offer_bound(mine, k, wofs);
+        if (tid == 0) ctl[2] = 0;
+        __syncthreads();
+        for (int i = tid; i < G; i += blockDim.x) {
+            const uint32_t v = vals[i];
+            if (v >= bound) {
+                const int pos = atomicAdd(&ctl[2], 1);
+                if (pos < RANK_MAX) surv[pos] = v;
+            }
+        }
+        __syncthreads();
+        const int got = ctl[2];   // >= k (uniform)
+        if (got <= RANK_MAX) {
+            for (int i = tid; i < got; i += blockDim.x) {
+                const uint32_t v = surv[i];
+                int gt = 0, ge = 0;
+                for (int j = 0; j < got; ++j) {
+                    const uint32_t u = surv[j];
+                    gt += (u > v);
+                    ge += (u >= v);
+                }
+                if (gt < k && k <= ge) thr[q] = ord2f(v);   // equal values may write: the same number
+            }
+            return;
+        }
+        __syncthreads();
+    }
     const uint32_t kth = radix_kth<uint32_t>(vals, G, k, hist, ctl);
     if (tid == 0) thr[q] = ord2f(kth);
 }
@@ -870,7 +948,15 @@ struct TopkScratch {
     u64* sub;     // SUB_MAX keys of LDS
     int* hist;    // 256 ints
     int* ctl;     // 4 ints
+    int stop;     // diagnostic build: return after phase `stop` (timing ablation); 0 = run to the end
 };
+// phase markers of the selection kernels: in the diagnostic build a kernel can be told to return after
+// phase n (results are then meaningless), which prices the phases by difference
+#ifdef ARTMIPS_DIAG
+#define SEL_PHASE(stop, n) do { if ((stop) == (n)) return; } while (0)
+#else
+#define SEL_PHASE(stop, n) do { } while (0)
+#endif
 
 __device__ __forceinline__ void write_topk(const u64* sorted, int n_sorted, const TopkOut& o) {
     for (int i = threadIdx.x; i < o.k; i += blockDim.x) {
@@ -905,15 +991,59 @@ __device__ void topk_finish(u64* keys, int M, bool in_lds, const int32_t* row_id
     const int tid = threadIdx.x;
     const int k = o.k;
     if (M <= 0) { write_topk(sc.sub, 0, o); return; }
+    // ---- wave-offer route (small k): a score bound from the waves' sorted thread maxima
+    // (wave_offer_bound), the keys at or above it finished and ranked by counting: one pass over the
+    // keys, no radix pass, no sorting network in LDS.
+    if (k <= 128 && (k + (int)(blockDim.x >> 6) - 1) / (int)(blockDim.x >> 6) <= 64) {
+        uint32_t mine = 0;
+        for (int i = tid; i < M; i += blockDim.x) {
+            const uint32_t v = (uint32_t)(keys[i] >> 32);
+            mine = v > mine ? v : mine;
+        }
+        const uint32_t bound = wave_offer_bound(mine, k, (uint32_t*)sc.hist);
+        if (tid == 0) sc.ctl[2] = 0;
+        __syncthreads();
+        for (int i = tid; i < M; i += blockDim.x) {
+            const u64 key = keys[i];
+            if ((uint32_t)(key >> 32) >= bound) {
+                const int pos = atomicAdd(&sc.ctl[2], 1);
+                if (pos < RANK_MAX) sc.sub[pos] = finish_key(key, row_ids);
+            }
+        }
+        __syncthreads();
+        const int got = sc.ctl[2];
+        __syncthreads();
+        SEL_PHASE(sc.stop, 4);
+        if (got <= RANK_MAX) {
+            // keys are distinct: the number of larger keys is the output position
+            for (int i = tid; i < got; i += blockDim.x) {
+                const u64 key = sc.sub[i];
+                int rank = 0;
+                for (int j = 0; j < got; ++j) rank += (sc.sub[j] > key);
+                if (rank < k) {
+                    store_score(o.scores, o.score_dtype, o.row * (long long)k + rank, key_score(key));
+                    o.ids[o.row * (long long)k + rank] = key_id(key);
+                }
+            }
+            for (int i = got + tid; i < k; i += blockDim.x) {   // fewer than k rows in all: pads
+                store_score(o.scores, o.score_dtype, o.row * (long long)k + i, -INFINITY);
+                o.ids[o.row * (long long)k + i] = 0x7fffffff;
+            }
+            return;
+        }
+        // massive ties or a degenerate bound: the routes below sort it out
+    }
     // ---- two-level route
     int ns = next_pow2(4 * k);
     if (ns < 512) ns = 512;
     if (ns <= SUB_MAX && M >= 2 * ns) {
+        SEL_PHASE(sc.stop, 6);
         uint32_t* sample = (uint32_t*)sc.sub;
         for (int i = tid; i < ns; i += blockDim.x) sample[i] = (uint32_t)(keys[i] >> 32);
         __syncthreads();
         // k sampled rows score >= bound, so the true k-th best score does too
         const uint32_t bound = radix_kth<uint32_t>(sample, ns, k, sc.hist, sc.ctl);
+        SEL_PHASE(sc.stop, 3);
         if (tid == 0) sc.ctl[2] = 0;
         __syncthreads();
         for (int i = tid; i < M; i += blockDim.x) {
@@ -926,16 +1056,19 @@ __device__ void topk_finish(u64* keys, int M, bool in_lds, const int32_t* row_id
         __syncthreads();
         const int got = sc.ctl[2];
         __syncthreads();
+        SEL_PHASE(sc.stop, 4);
         if (got <= SUB_MAX) {
             const int P = next_pow2(got < 2 ? 2 : got);
             for (int i = got + tid; i < P; i += blockDim.x) sc.sub[i] = 0ull;
             __syncthreads();
             bitonic_sort_desc<u64>(sc.sub, P);
+            SEL_PHASE(sc.stop, 5);
             write_topk(sc.sub, got, o);
             return;
         }
         // too many survivors (skewed sample or massive score ties): unconditional routes below
     }
+    SEL_PHASE(sc.stop, 7);
     if (row_ids != nullptr) {
         for (int i = tid; i < M; i += blockDim.x) keys[i] = finish_key(keys[i], row_ids);
         __syncthreads();
@@ -999,12 +1132,18 @@ struct SelectArgs {
     long long out_row0;     // first output row of this query tile
     int* status;            // bit0: a candidate list overflowed its cap; bit1: key scratch too small
     unsigned long long* cand_total;
+    int stop_after;         // diagnostic build only (SEL_PHASE)
+    // Optional: the last workgroup of the launch to finish copies the 4 status words to `publish`
+    // (pinned host memory as the device sees it), which saves the search a copy command behind the
+    // pipeline.  done_counter is a device word that is zero before the launch and zero again after it.
+    int* publish;
+    int* done_counter;
 };
 
 // 32-bit scores radix-selected in LDS by select_kernel's "score route" (112 KiB, shared with skeys)
 constexpr int SCORE_MAX = 28672;
 
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
+__device__ __forceinline__ void select_body(const SelectArgs& a) {
     __shared__ __attribute__((aligned(16))) uint32_t big[SCORE_MAX];
     static_assert(SCORE_MAX * 4 >= SORT_MAX * 8, "skeys lives in the same LDS as the scores");
     u64* const skeys = (u64*)big;
@@ -1069,6 +1208,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         if (tid == 0) a.refine_thr[q] = fmaxf(a.refine_thr[q], ord2f(kth));
         return;
     }
+    SEL_PHASE(a.stop_after, 1);
     if (ovf) atomicOr(a.status, 1);
     if (tid == 0) atomicAdd(a.cand_total, (unsigned long long)M);
     __syncthreads();
@@ -1088,7 +1228,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
     const int cpt = (M + nt - 1) / nt;
     const int e_begin = tid * cpt;
     const int e_end = (e_begin + cpt < M) ? e_begin + cpt : M;
-    TopkScratch sc{skeys, sub, hist, ctl};
+    TopkScratch sc{skeys, sub, hist, ctl, a.stop_after};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, a.out_row0 + q, a.k};
 
     // ---- score route (more candidates than the LDS sort holds, e.g. k = 1000): only the 32-bit
@@ -1150,7 +1290,32 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
         }
     }
     __syncthreads();
+    SEL_PHASE(a.stop_after, 2);
     topk_finish(dst, M, in_lds, a.ids, sc, o);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a) {
+    select_body(a);
+    if (a.publish != nullptr) {
+        // every thread of this workgroup has raised what it had to raise in the status words
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int done = atomicAdd(a.done_counter, 1);
+            if (done == (int)gridDim.x - 1) {   // all other workgroups' status updates are visible
+                __threadfence();
+                const int flags = atomicOr(a.status, 0);
+                const unsigned long long cand = atomicAdd(a.cand_total, 0ull);
+                volatile int* out = a.publish;
+                out[0] = flags;
+                out[1] = 0;
+                out[2] = (int)(uint32_t)cand;
+                out[3] = (int)(uint32_t)(cand >> 32);
+                atomicExch(a.done_counter, 0);
+                __threadfence_system();
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1208,7 +1373,7 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_kernel(MergeArgs a) {
     }
     __syncthreads();
     const int M = s_fill;
-    TopkScratch sc{skeys, sub, hist, ctl};
+    TopkScratch sc{skeys, sub, hist, ctl, 0};
     TopkOut o{a.out_scores, a.score_dtype, a.out_ids, q, a.k};
     topk_finish(dst, M, in_lds, nullptr, sc, o);
 }
