@@ -876,8 +876,9 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
         p.stage_lds = !(nw == 8 && nq == 2) && per_list <= 4.0 * staging_slots;
         p.refine = period;
     };
-    // Large k: pass 0 at the fitted sample_div (16 where the scan is MFMA-bound) is 1/16 of the scan's
-    // own cost and still leaves k * 16 survivors per query.  The FILTER scan therefore runs in two
+    // Where the lists are written directly (many survivors per lane: large k, or large batches at any
+    // k): pass 0 at the fitted sample_div (16 at top-1000 where the scan is MFMA-bound, 38 at top-100)
+    // is 1/16 of the scan's own cost and still leaves k * 16 survivors per query.  The FILTER scan therefore runs in two
     // parts: every P-th tile first, then the k-th best score among THOSE survivors (rank k * P of the
     // whole shard) replaces the threshold for the other tiles.  That makes a 4 x coarser sample
     // affordable: with P = 8 and sample_div = 64 the two parts keep 8k + 7k candidates per query at
@@ -887,11 +888,11 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     int period = 8;
     if (const int r = diag_int("ARTMIPS_REFINE", -1); r >= 0) period = (r == 4 || r == 8) ? r : 0;
     bool two_part = false;
-    if (period && k > 128 && p.n_tiles >= 64ll * p.grid) {
+    if (period && p.n_tiles >= 64ll * p.grid) {
         // (part A's survivors, k * sd_r / P per query, must fit the refinement's LDS: SCORE_MAX)
         long long sd_r = std::min<long long>(std::min<long long>(128, sample_div * 4), 20000ll * period / k);
         if (const int sd = diag_int("ARTMIPS_SAMPLE_DIV", 0)) sd_r = std::max(4, sd);
-        if (sd_r >= sample_div) {
+        if (sd_r >= 2 * sample_div) {   // worth a second launch only if pass 0 at least halves
             with_sample(sd_r, period);
             two_part = p.pass0 && !p.stage_lds;
         }
