@@ -23,6 +23,10 @@ q = torch.randn((nq, 768), device="cuda").half()
 ref = None
 variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["0", "4", "8", "0", "8"]
 for v in variants:   # REFINE or REFINE:SAMPLE_DIV
+    v, _, nw = v.partition("/")          # REFINE[:SAMPLE_DIV][/NW]  (NW: ARTMIPS_NW, 44 = 4 x 4 gangs, 88 = 8 x 2)
+    os.environ.pop("ARTMIPS_NW", None)
+    if nw:
+        os.environ["ARTMIPS_NW"] = nw
     r, _, sd = v.partition(":")
     os.environ["ARTMIPS_REFINE"] = r
     os.environ.pop("ARTMIPS_SAMPLE_DIV", None)
@@ -34,7 +38,7 @@ for v in variants:   # REFINE or REFINE:SAMPLE_DIV
     same = True if ref is None else bool(torch.equal(ids, ref))
     if ref is None:
         ref = ids.clone()
-    print("refine", v, "cand/query %.0f" % (i["last_candidates"] / nq), "scan ms %.3f" % i["last_scan_ms"],
+    print("refine", v, "nw", nw or "-", "cand/query %.0f" % (i["last_candidates"] / nq), "scan ms %.3f" % i["last_scan_ms"],
           "pipeline ms %.3f" % i["last_total_ms"], "ids identical", same, flush=True)
     if not same:
         sys.exit(1)
