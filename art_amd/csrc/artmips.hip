@@ -1085,7 +1085,7 @@ struct ShardCall {
     int32_t* out_ids;
     hipStream_t st;
     bool record_stats;
-    bool host_status = true;  // copy the status words to pinned host memory behind the pipeline
+    bool host_status = true;  // the last select launch publishes the status words to pinned host memory
     int* status_dev = nullptr;  // 16 status words on the shard's device, 8-byte aligned; NULL = the
                                 // shard's own block (the async path raises them in the packed tail)
     unsigned char* static_scratch = nullptr;  // allocation-free form: the workspace is carved from this
@@ -1097,7 +1097,7 @@ struct ShardCall {
 };
 
 // Plan, size the scratch and enqueue the whole pipeline of one shard (every query tile) plus the
-// copy of its status words to pinned host memory.  Does not wait.
+// publication of its status words in pinned host memory (by the last select launch).  Does not wait.
 static int shard_enqueue(artmips* h, ShardCall& c) {
     Shard& s = h->sh[c.slot];
     const Generation& gen = s.live;
