@@ -95,6 +95,45 @@ def test_gang_launches_vs_oracle(gu, n, q, k, storage):
     eng.close()
 
 
+# ---- ties through the two-part scan and through the small-k selection: integer data, bit-exact
+def test_two_part_scan_integer_ties(gu):
+    """Gang of 4 + a smaller launch over integer data: the refined threshold (k-th best score of the
+    first part) sits on a tie group of thousands of rows, every one of which must survive `>=` in the
+    second part; ids and scores bit-exact against the oracle's (score desc, id asc)."""
+    n, q, dim, k = 70000, 1100, 768, 200
+    rng = np.random.Generator(np.random.PCG64(9100))
+    rows = rng.integers(-1, 2, size=(n, dim)).astype(np.float16)
+    queries = rng.integers(-1, 2, size=(q, dim)).astype(np.float16)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    es, ei, _ = orc.exact_topk(queries.astype(np.float64), rows.astype(np.float64), ids, k)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(s, es.astype(np.float32))
+    eng.close()
+
+
+@pytest.mark.parametrize("n,q,k", [(20000, 70, 32), (3000, 5, 100)])
+def test_small_k_every_score_equal(gu, n, q, k):
+    """All rows identical: every row ties on every query, nothing can be filtered, and the small-k
+    selection (bound from the waves' sorted thread maxima, survivors ranked by counting) meets far
+    more keys at its bound than it ranks by counting and must fall back.  Expected: the k smallest ids."""
+    rng = np.random.Generator(np.random.PCG64(9200 + n))
+    row = (rng.standard_normal(768) * 0.05).astype(np.float16)
+    rows = np.tile(row, (n, 1))
+    queries = rng.standard_normal((q, 768)).astype(np.float16)
+    ids = (rng.permutation(n) + 7).astype(np.int32)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    want = np.sort(ids)[:k]
+    for qi in range(q):
+        np.testing.assert_array_equal(i[qi], want)
+        assert np.all(s[qi] == s[qi][0])
+    exact = queries.astype(np.float64) @ row.astype(np.float64)
+    np.testing.assert_allclose(s[:, 0], exact, rtol=REL_TOL, atol=1e-6)
+    eng.close()
+
+
 # ---- BASELINE config 5 at oracle size: fp32 storage, top-1000, more than one query tile (the fp32
 # scan stages survivors in LDS and flushes them many times per lane at this k)
 @pytest.mark.parametrize("n,q,k", [(30000, 150, 1000), (120000, 70, 1000)])
