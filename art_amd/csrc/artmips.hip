@@ -658,8 +658,9 @@ static void launch_scatter(const void* src, int src_dtype, const long long* ids,
                      (sizeof(T) == 2 || src_dtype == ARTMIPS_F32 || src_row % 8 == 0);
     if (vec) {
         // enough workgroups for every CU even from a 1,024-row batch, 8 rows each for large ones
+        // (at most 2,048 workgroups: each ends with one atomic add on a word all of them share)
         const int rpw = (int)std::max<long long>(1, std::min<long long>(8, n / 1024));
-        const int grid = (int)std::min<long long>((n + rpw - 1) / rpw, 8192);
+        const int grid = (int)std::min<long long>((n + rpw - 1) / rpw, 2048);
 #define SCATTER_VEC(S)                                                                                  \
     hipLaunchKernelGGL((scatter_rows_vec_kernel<T, S>), dim3(grid), dim3(256), 0, st, (const S*)src, ids, n, \
                        id_base, (long long)g.row0, (long long)g.n_rows, dim, (T*)g.rows, g.ids, g.meta, rpw)
