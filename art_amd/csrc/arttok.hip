@@ -75,10 +75,15 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict_
     }
 }
 
-// The same gather with 16-byte stores: every lane takes 4 consecutive tokens of the item (its four loads
-// are independent and the wave's loads cover one contiguous run of the token file) and writes one int4
-// of the padded row, so a wave covers 256 output tokens per step instead of 64.  Needs 16-byte aligned
-// output rows (max_len % 4 == 0, aligned base); the host falls back to gather_tokens_kernel otherwise.
+// The same gather with 16-byte stores: every lane takes 4 consecutive tokens of an item (its four loads
+// are independent and the lanes' loads cover one contiguous run of the token file) and writes one int4
+// of the padded row.  An item is a chain of dependent loads (id -> size and offset -> tokens), about
+// 2.5 us with nothing else in flight, and one item per wave at a time made that chain the whole cost
+// (361,000 items: 58 us even for 16-token rows).  So a wave works on several items at once: `lpi` lanes
+// per item (the power of two that covers max_len / 4, at most 64), 64 / lpi items side by side, and four
+// such groups per step, all their metadata requested before any token is copied.
+// Needs 16-byte aligned output rows (max_len % 4 == 0, aligned base); the host falls back to
+// gather_tokens_kernel otherwise.
 template <typename E>
 __global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restrict__ tokens,
                                                                 const int64_t* __restrict__ offsets,
@@ -86,28 +91,44 @@ __global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restr
                                                                 int64_t n_items, const int32_t* __restrict__ ids,
                                                                 int64_t n, int32_t id_base, int max_len,
                                                                 int32_t pad, int32_t* __restrict__ out_tokens,
-                                                                int32_t* __restrict__ out_lens) {
+                                                                int32_t* __restrict__ out_lens, int lpi) {
     const int lane = threadIdx.x & 63;
+    const int sub = lane / lpi, sl = lane - sub * lpi;   // item slot of this lane in the wave, lane in the item
+    const int ipw = 64 / lpi;                            // items per wave and group
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t i = wave; i < n; i += n_waves) {
-        const int64_t item = (int64_t)ids[i] - id_base;
-        int4* row = (int4*)(out_tokens + i * max_len);
-        int len = -1;
-        const E* src = nullptr;
-        if (item >= 0 && item < n_items) {
-            len = sizes[item] < max_len ? sizes[item] : max_len;
-            src = tokens + offsets[item];
+    constexpr int U = 4;
+    for (int64_t base = wave * ipw * U; base < n; base += n_waves * ipw * U) {
+        int64_t idx[U];
+        int len[U];
+        const E* src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = base + u * ipw + sub;
+            len[u] = -1;
+            src[u] = nullptr;
+            if (idx[u] < n) {
+                const int64_t item = (int64_t)ids[idx[u]] - id_base;
+                if (item >= 0 && item < n_items) {
+                    len[u] = sizes[item] < max_len ? sizes[item] : max_len;
+                    src[u] = tokens + offsets[item];
+                }
+            }
         }
-        for (int t = lane * 4; t < max_len; t += 256) {
-            int4 v;
-            v.x = (t < len) ? (int32_t)src[t] : pad;
-            v.y = (t + 1 < len) ? (int32_t)src[t + 1] : pad;
-            v.z = (t + 2 < len) ? (int32_t)src[t + 2] : pad;
-            v.w = (t + 3 < len) ? (int32_t)src[t + 3] : pad;
-            row[t >> 2] = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (idx[u] >= n) continue;
+            int4* row = (int4*)(out_tokens + idx[u] * max_len);
+            for (int t = sl * 4; t < max_len; t += lpi * 4) {
+                int4 v;
+                v.x = (t < len[u]) ? (int32_t)src[u][t] : pad;
+                v.y = (t + 1 < len[u]) ? (int32_t)src[u][t + 1] : pad;
+                v.z = (t + 2 < len[u]) ? (int32_t)src[u][t + 2] : pad;
+                v.w = (t + 3 < len[u]) ? (int32_t)src[u][t + 3] : pad;
+                row[t >> 2] = v;
+            }
+            if (sl == 0) out_lens[idx[u]] = len[u];
         }
-        if (lane == 0) out_lens[i] = len;
     }
 }
 
@@ -181,15 +202,19 @@ extern "C" int arttok_gather(arttok_t* h, const int32_t* ids_dev, int64_t n, int
     TokDeviceGuard g(h->device);
     hipStream_t st = (hipStream_t)stream;
     const int waves_per_block = 4;
-    const int64_t want = (n + waves_per_block - 1) / waves_per_block;
-    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
     const bool vec = (max_len % 4 == 0) && (((uintptr_t)out_tokens) & 15) == 0;
+    // vector kernel: lanes per item = the power of two covering max_len / 4 (at most a whole wave)
+    int lpi = 1;
+    while (lpi < 64 && lpi * 4 < max_len) lpi <<= 1;
+    const int64_t per_wave = vec ? 4 * (64 / lpi) : 1;   // items a wave takes per step
+    const int64_t want = (n + waves_per_block * per_wave - 1) / (waves_per_block * per_wave);
+    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
 #define LAUNCH(E)                                                                                      \
     do {                                                                                               \
         if (vec)                                                                                       \
             hipLaunchKernelGGL(gather_tokens_vec_kernel<E>, dim3(grid), dim3(64 * waves_per_block), 0, st, \
                                (const E*)h->tokens, (const int64_t*)h->offsets, (const int32_t*)h->sizes,  \
-                               h->n_items, ids_dev, n, id_base, max_len, pad, out_tokens, out_lens);   \
+                               h->n_items, ids_dev, n, id_base, max_len, pad, out_tokens, out_lens, lpi); \
         else                                                                                           \
             hipLaunchKernelGGL(gather_tokens_kernel<E>, dim3(grid), dim3(64 * waves_per_block), 0, st, \
                                (const E*)h->tokens, (const int64_t*)h->offsets, (const int32_t*)h->sizes,  \
