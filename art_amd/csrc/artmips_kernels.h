@@ -1477,7 +1477,8 @@ __global__ __launch_bounds__(256) void scatter_rows_vec_kernel(const S* __restri
             for (int u = 0; u < U; ++u) {
                 const long long pos = id[u] - id_base - shard_row0;
                 if (!live[u] || pos < 0 || pos >= shard_rows) continue;   // (another shard owns this row)
-                *(TV*)(rows + pos * dim + col[u] * EPC) = o[u];
+                // (non-temporal: the rows are not read again before the next search streams the whole shard)
+                __builtin_nontemporal_store(o[u], (TV*)(rows + pos * dim + col[u] * EPC));
                 if (col[u] == 0) {
                     const int32_t old = atomicExch(&row_ids[pos], (int32_t)id[u]);
                     if (old != ID_SENTINEL) ++dups; else ++fresh;

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restr
                 v.y = (t + 1 < len[u]) ? (int32_t)src[u][t + 1] : pad;
                 v.z = (t + 2 < len[u]) ? (int32_t)src[u][t + 2] : pad;
                 v.w = (t + 3 < len[u]) ? (int32_t)src[u][t + 3] : pad;
-                row[t >> 2] = v;
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, (v4i*)&row[t >> 2]);   // written once, read by another kernel later
             }
             if (sl == 0) out_lens[idx[u]] = len[u];
         }
