@@ -1065,8 +1065,10 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     DEBUG_STEP(st, "scan<FILTER> grid=%d nq=%d nw=%d stg=%d cap=%d tiles=%lld rows=%lld q_count=%d q_rows=%d",
                p.grid, p.nq, p.nw, (int)p.stage_lds, p.cap, p.n_tiles, (long long)gen.n_rows, q_count, q_rows);
 
-    // few candidates per query (small k): 4 waves sort faster than 16 (cheaper barriers)
-    const int sel_threads = (k <= 128 && p.pass0) ? 256 : SEL_THREADS;
+    // small k: the selection is the gather of the candidates plus a few barriers; 8 waves halve the
+    // gather of 4 and keep the barriers cheap (select at the headline shape 28.6 us with 256 threads,
+    // 21.3 with 512, 19.6 with 1,024; on a 1/8 shard 18.7 / 15.6 / 16.0)
+    const int sel_threads = (k <= 128 && p.pass0) ? std::max(64, diag_int("ARTMIPS_SEL_THREADS", 512)) : SEL_THREADS;
     hipLaunchKernelGGL(select_kernel, dim3(q_count), dim3(sel_threads), 0, st, sa);
     HIP_TRY(hipGetLastError());
     DEBUG_STEP(st, "select grid=%d threads=%d k=%d", q_count, sel_threads, k);
