@@ -8,9 +8,19 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ARTMIPS_LIBRARY names another build of the same ABI: the measurement scripts under tools/ point it at
-# lib/libartmips_diag.so, the only build that reads the ARTMIPS_* diagnostic knobs
-LIB_PATH = os.environ.get("ARTMIPS_LIBRARY") or os.path.join(_HERE, "lib", "libartmips.so")
+# The product loads lib/libartmips.so and nothing else.  Another build of the same ABI (the measurement
+# scripts under tools/ use lib/libartmips_diag.so, the only build that reads the ARTMIPS_* diagnostic
+# knobs) is loaded only on a double opt-in: ARTMIPS_DIAGNOSTICS=1 AND ARTMIPS_LIBRARY=path.
+# A stray ARTMIPS_LIBRARY alone changes nothing (it is reported once and ignored).
+LIB_PATH = os.path.join(_HERE, "lib", "libartmips.so")
+if os.environ.get("ARTMIPS_LIBRARY"):
+    if os.environ.get("ARTMIPS_DIAGNOSTICS") == "1":
+        LIB_PATH = os.environ["ARTMIPS_LIBRARY"]
+    else:
+        import warnings
+
+        warnings.warn("ARTMIPS_LIBRARY is set but ARTMIPS_DIAGNOSTICS=1 is not: ignored, loading %s" % LIB_PATH,
+                      RuntimeWarning)
 DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libartmips_diag.so")
 NOALLOC_SCRATCH_BYTES = 64 << 20  # ARTMIPS_NOALLOC_SCRATCH_BYTES
 

@@ -247,6 +247,11 @@ static void free_generation(Generation& g) {
 // where large k occurs: 2-byte storage, dim 768)
 enum { MODE_GROUPMAX4 = 2 };
 
+// grid == 0 is the PREPARE form: the kernel's dynamic-LDS attribute is set for the current device and
+// nothing is launched.  artmips_create prepares every instantiation its handle can launch
+// (prepare_kernels), so that no search call ever changes a function attribute: a search can then be
+// enqueued under HIP graph capture, and the first call of a shape costs what every other one does.
+// The flags keep the lazy path as a fallback for a device the handle was not created for.
 template <typename T, int DIM, int NSTAGE, int AUX, int NQ = 1, int STG = 1, int NW = 4>
 static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * TILE_ROWS * DIM * sizeof(T) + STAGING_BYTES;
@@ -256,35 +261,28 @@ static int launch_scan_t(int mode, const ScanArgs& a, int grid, hipStream_t st) 
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= ARTMIPS_MAX_DEVICES * 4) return fail(ARTMIPS_ERR_ARG, "device %d", dev);
-    if (mode == MODE_FILTER) {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_FILTER, AUX, NQ, STG, NW>;
-        if (!attr_done[dev][0]) {
+    auto go = [&](auto kfn, int which) -> int {
+        if (!attr_done[dev][which]) {
             HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-            attr_done[dev][0] = true;
+            attr_done[dev][which] = true;
         }
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+        if (grid > 0) hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+        return 0;
+    };
+    int rc = 0;
+    if (mode == MODE_FILTER) {
+        rc = go(scan_kernel<T, DIM, NSTAGE, MODE_FILTER, AUX, NQ, STG, NW>, 0);
     } else if (mode == MODE_GROUPMAX4) {
         if constexpr (DIM == 768 && sizeof(T) == 2 && STG == 0) {
-            auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW, 4>;
-            if (!attr_done[dev][2]) {
-                HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-                attr_done[dev][2] = true;
-            }
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+            rc = go(scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW, 4>, 2);
         } else {
             return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: no top-4 pass 0 for this shape");
         }
     } else {
-        auto kfn = scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW>;
-        if (!attr_done[dev][1]) {
-            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-            attr_done[dev][1] = true;
-        }
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds, st, a);
+        rc = go(scan_kernel<T, DIM, NSTAGE, MODE_GROUPMAX, AUX, NQ, STG, NW>, 1);
     }
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -346,6 +344,35 @@ static int max_nq(int dim, int dtype) { return dtype == ARTMIPS_F32 ? 1 : (dim =
 static bool dim_supported(int dim, int dtype) {
     if (dtype == ARTMIPS_F32) return dim == 768 || dim == 128;
     return dim == 768 || dim == 1024 || dim == 128;
+}
+
+static std::atomic<bool> g_kth_attr[ARTMIPS_MAX_DEVICES * 4] = {};
+
+// With device `dev` current: set the function attributes of every kernel instantiation a handle of
+// this (dim, dtype) can launch (see launch_scan_t).  Shapes that are not built answer
+// ARTMIPS_ERR_UNSUPPORTED from the dispatch, which is not an error here.
+static int prepare_kernels(int dev, int dim, int dtype) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int gang = 1; gang <= 2; ++gang) {       // gang > 1 selects the gang instantiations
+        a.gang = gang;
+        for (int nw = 4; nw <= 8; nw += 4)
+            for (int nq = 1; nq <= MAX_NQ; ++nq)
+                for (int stg = 0; stg <= 1; ++stg)
+                    for (int mode = 0; mode <= 2; ++mode) {
+                        const int rc = launch_scan(dtype, dim, nq, nw, stg != 0, mode, a, 0, nullptr);
+                        if (rc == ARTMIPS_ERR_HIP) return rc;
+                    }
+    }
+    if (dev >= 0 && dev < ARTMIPS_MAX_DEVICES * 4 && !g_kth_attr[dev]) {
+        // 16,384 sample values (k in (1024, 2048]) are 64 KiB of dynamic LDS on top of the static
+        // histogram: above the default limit of a launch
+        HIP_TRY(hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    128 * 1024));
+        g_kth_attr[dev] = true;
+    }
+    g_err[0] = 0;   // the "unsupported" answers above are not this call's error
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,6 +446,10 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
             artmips_destroy(h);
             return ARTMIPS_ERR_HIP;
         }
+        if (prepare_kernels(s.dev, dim, storage_dtype) != 0) {
+            artmips_destroy(h);
+            return ARTMIPS_ERR_HIP;
+        }
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -431,26 +462,30 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
         memset(s.status_host, 0, 64);
     }
     // One process, several devices (the reference's model, art_index.py:204,254-255): queries and
-    // candidate lists travel between the shards' devices by peer copies, which need peer access.
+    // candidate lists travel between the shards' devices by peer copies.
     for (int i = 0; i < n_dev; ++i) {
         for (int j = 0; j < n_dev; ++j) {
             const int a = h->sh[i].dev, b = h->sh[j].dev;
             if (a == b) continue;
+            // Best effort: no kernel of this library dereferences another device's memory; queries,
+            // candidate lists and scatter batches cross devices by hipMemcpyPeerAsync only, which the
+            // runtime stages through the host where peer access is unavailable (IOMMU / ACS, mixed
+            // topologies).  Peer access makes those copies direct; a platform without it still works,
+            // and a copy that really cannot be made fails where it is issued.
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
-                artmips_destroy(h);
-                return fail(ARTMIPS_ERR_UNSUPPORTED,
-                            "device %d cannot access the memory of device %d (no peer access): the "
-                            "one-process / many-devices mode needs it; use one process per GPU instead", a, b);
+                (void)hipGetLastError();
+                fprintf(stderr, "[artmips] no peer access from device %d to device %d: copies between them "
+                                "will be staged by the runtime\n", a, b);
+                continue;
             }
             DeviceGuard g(a);
             const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-            if (e == hipErrorPeerAccessAlreadyEnabled) {
-                (void)hipGetLastError();  // torch or an earlier handle enabled it: fine
-            } else if (e != hipSuccess) {
-                artmips_destroy(h);
-                return fail(ARTMIPS_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", a, b,
-                            hipGetErrorString(e));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled (torch or an earlier handle): fine
+                if (e != hipErrorPeerAccessAlreadyEnabled)
+                    fprintf(stderr, "[artmips] hipDeviceEnablePeerAccess(%d -> %d): %s; copies between them "
+                                    "will be staged by the runtime\n", a, b, hipGetErrorString(e));
             }
         }
     }
@@ -783,6 +818,8 @@ extern "C" int artmips_finalize(artmips_t* h) {
 // ---------------------------------------------------------------------------------------------
 // per-shard search pipeline
 // ---------------------------------------------------------------------------------------------
+constexpr int STATUS_UNPUBLISHED = -1;   // never a value of the flag word (bits 0 and 1 only)
+
 struct Plan {
     bool pass0;
     int grid0;            // blocks of the GROUPMAX scan
@@ -981,15 +1018,10 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         size_t kth_lds = 8;
         while (kth_lds < (size_t)n_values) kth_lds <<= 1;
         const int kth_threads = (n_values <= 4096) ? 256 : SEL_THREADS;
-        if (kth_lds * 4 > 48 * 1024) {
-            // 16,384 sample values (k in (1024, 2048]) are 64 KiB of dynamic LDS on top of the static
-            // histogram: above the default limit of a launch
-            static std::atomic<bool> kth_attr[ARTMIPS_MAX_DEVICES * 4] = {};
-            if (!kth_attr[s.dev]) {
-                HIP_TRY(hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            128 * 1024));
-                kth_attr[s.dev] = true;
-            }
+        if (kth_lds * 4 > 48 * 1024 && !g_kth_attr[s.dev]) {   // (set in artmips_create: prepare_kernels)
+            HIP_TRY(hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        128 * 1024));
+            g_kth_attr[s.dev] = true;
         }
         hipLaunchKernelGGL(kth_kernel, dim3(qt), dim3(kth_threads), kth_lds * 4, st,
                            ws.gmax, n_values, p.nq, k, q_count, ws.thr, clear);
@@ -1218,7 +1250,9 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
         if ((rc = ensure(s.thr, sz_thr))) return rc;
         if (!s.status.p) {
             if ((rc = ensure(s.status, 64))) return rc;
-            HIP_TRY(hipMemset(s.status.p, 0, 64));   // word 8 is select_kernel's done counter
+            // word 8 is select_kernel's done counter; zeroed on the stream the pipeline runs on (the
+            // null stream orders nothing against a non-blocking stream)
+            HIP_TRY(hipMemsetAsync(s.status.p, 0, 64, c.st));
         }
         if (sz_gmax && (rc = ensure(s.gmax, sz_gmax))) return rc;
         if ((rc = ensure(s.counts, sz_counts))) return rc;
@@ -1240,6 +1274,10 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
     c.status_used = status;
     c.n_tiles_q = 0;
     const int total_launches = n_launches + (int)overflow_launches.size();
+    // the last select launch publishes the status words to the pinned host block: a sentinel there
+    // makes a publication that never happened visible (shard_complete) instead of letting the previous
+    // search's "no overflow" stand in for it
+    if (c.host_status && !c.static_scratch) ((volatile int*)s.status_host)[0] = STATUS_UNPUBLISHED;
     for (int li = 0; li < total_launches; ++li, ++c.n_tiles_q) {
         const Launch& l = li < 64 ? launches[li] : overflow_launches[li - 64];
         const bool publish = c.host_status && !c.static_scratch && li == total_launches - 1;
@@ -1262,7 +1300,9 @@ static int shard_complete(artmips* h, ShardCall& c, bool* overflow) {
     HIP_TRY(hipStreamSynchronize(c.st));
     const auto t_syn = std::chrono::steady_clock::now();
     *overflow = false;
-    const int status = s.status_host[0];
+    const int status = ((volatile int*)s.status_host)[0];
+    if (status == STATUS_UNPUBLISHED)
+        return fail(ARTMIPS_ERR_STATE, "internal: the pipeline ended without publishing its status words");
     if (status & 2) return fail(ARTMIPS_ERR_STATE, "internal: key scratch too small");
     if (status & 1) { *overflow = true; return 0; }
     if (c.record_stats) {
@@ -1575,7 +1615,10 @@ static int multi_enqueue(artmips* h, const std::vector<int>& used, const void* q
         Shard& s = h->sh[slot];
         DeviceGuard g(s.dev);
         int r = 0;
-        const bool remote = (s.dev != s0.dev);
+        // diagnostic build: ARTMIPS_FORCE_REMOTE=1 takes the other-device branch (peer copy of the
+        // queries, private list, peer copy of the list) for shards on slot 0's own device too, so that
+        // a one-GPU box can execute it (tests/test_search3_gpu.py)
+        const bool remote = (s.dev != s0.dev) || diag_int("ARTMIPS_FORCE_REMOTE", 0) != 0;
         const void* q_here = q_dev;
         int32_t* list = gathered + (size_t)u * words;
         HIP_TRY(hipStreamWaitEvent(s.stream, s0.ev_ready, 0));

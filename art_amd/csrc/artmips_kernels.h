@@ -50,6 +50,7 @@ enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
 #else
 #define ARTMIPS_MFMA_PAD "s_nop 1\n\t"
 #endif
+
 template <typename T> struct Elem;
 template <> struct Elem<_Float16> {
     typedef half8 V;
@@ -185,8 +186,11 @@ struct ScanArgs {
     // only, STG == 0).
     int tile_skip;
     int counts_continue;
-    int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE; results are
-                          // then meaningless): 1 = no refill DMA in the loop, 2 = no barrier, 4 = no compute
+    int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE).  Bits 1..32 switch
+                          // parts of the loop off (results are then meaningless): 1 = no refill DMA, 2 = no
+                          // barrier, 4 = no compute, 8 = no LDS reads, 16 = no filter, 32 = reads never waited
+                          // for.  Bits 64..256 select code variants with identical results, for A/B runs in one
+                          // process: 64 = DMA pieces one by one, 256 = no one-branch pre-check in the filter
 };
 
 // LDS image of a stage (16 rows): the rows as they lie in memory (row-major, contiguous), cut into
@@ -195,28 +199,90 @@ struct ScanArgs {
 // the 16 bank slots (conflict-free ds_read_b128, profiles/r01_k_pmc_sq_counters.json).  Lane group g
 // multiplies chunk 4s+g in k-step s.  (An "8 rows x 128 B per piece" image was measured too and was
 // no faster: profiles/r01_b_scan_sweep.txt.)
-template <int AUX> __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
-}
-
 // LDS-DMA with a scalar base and a 32-bit per-lane offset (no vector address arithmetic at all).
 // hipcc does not select this addressing form for the builtin, hence inline asm.  M0 (the LDS
 // destination) is compiler-reserved: it is saved, written and restored inside the one statement
-// that uses it.  hipcc neither counts this load nor pads its hazards: the opening s_nop 4 covers a
+// that uses it.  hipcc neither counts these loads nor pads their hazards: the opening s_nop 4 covers a
 // base that a vector instruction produced, s_nop 0 the M0 write, and the caller waits with vmcnt.
-template <int AUX>
-__device__ __forceinline__ void glds16_saddr(const void* base, uint32_t lane_off, uint32_t lds_dst) {
+// The instruction adds its immediate offset field to BOTH addresses (the
+// global source and the LDS destination), so consecutive 1-KiB pieces of a stage can share one M0 value:
+// piece i of a group uses offset i*1024 - DMA_BIAS, its lane offset is pre-biased by the opposite amount
+// and M0 holds the group's first destination + DMA_BIAS (offsets span [-2048, 3072] of the 13-bit signed
+// field, so a group has up to 6 pieces).  One M0 save / write / restore and one hazard pad per GROUP
+// instead of per piece: the scalar instructions around a piece cost the issuing wave as much as the
+// piece itself when it is the only wave on its SIMD.
+constexpr int DMA_BIAS = 2048;
+#define ARTMIPS_GLDS_LINE(op, off, nt) "global_load_lds_dwordx4 %" #op ", %2 offset:" #off nt "\n\t"
+#define ARTMIPS_GLDS_HEAD "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+#define ARTMIPS_GLDS_TAIL "s_mov_b32 m0, %0"
+template <int AUX, int N>
+__device__ __forceinline__ void glds16_group(const void* base, const uint32_t* voff, uint32_t m0_val) {
     static_assert(AUX == 0 || AUX == 2, "asm DMA path knows the default and the nt policy");
+    static_assert(N >= 1 && N <= 6 && N != 5, "a group is 1, 2, 3, 4 or 6 pieces");
+    uint32_t keep;
+#define ARTMIPS_GLDS_BODY(NT)                                                                                 \
+    if constexpr (N == 1)                                                                                      \
+        asm volatile(ARTMIPS_GLDS_HEAD ARTMIPS_GLDS_LINE(3, -2048, NT) ARTMIPS_GLDS_TAIL                        \
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff[0]) : "memory");                         \
+    else if constexpr (N == 2)                                                                                 \
+        asm volatile(ARTMIPS_GLDS_HEAD ARTMIPS_GLDS_LINE(3, -2048, NT) ARTMIPS_GLDS_LINE(4, -1024, NT)          \
+                     ARTMIPS_GLDS_TAIL                                                                         \
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff[0]), "v"(voff[1]) : "memory");           \
+    else if constexpr (N == 3)                                                                                 \
+        asm volatile(ARTMIPS_GLDS_HEAD ARTMIPS_GLDS_LINE(3, -2048, NT) ARTMIPS_GLDS_LINE(4, -1024, NT)          \
+                     ARTMIPS_GLDS_LINE(5, 0, NT) ARTMIPS_GLDS_TAIL                                             \
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff[0]), "v"(voff[1]), "v"(voff[2])          \
+                     : "memory");                                                                              \
+    else if constexpr (N == 4)                                                                                 \
+        asm volatile(ARTMIPS_GLDS_HEAD ARTMIPS_GLDS_LINE(3, -2048, NT) ARTMIPS_GLDS_LINE(4, -1024, NT)          \
+                     ARTMIPS_GLDS_LINE(5, 0, NT) ARTMIPS_GLDS_LINE(6, 1024, NT) ARTMIPS_GLDS_TAIL               \
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),         \
+                       "v"(voff[3]) : "memory");                                                               \
+    else                                                                                                       \
+        asm volatile(ARTMIPS_GLDS_HEAD ARTMIPS_GLDS_LINE(3, -2048, NT) ARTMIPS_GLDS_LINE(4, -1024, NT)          \
+                     ARTMIPS_GLDS_LINE(5, 0, NT) ARTMIPS_GLDS_LINE(6, 1024, NT) ARTMIPS_GLDS_LINE(7, 2048, NT)  \
+                     ARTMIPS_GLDS_LINE(8, 3072, NT) ARTMIPS_GLDS_TAIL                                          \
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),         \
+                       "v"(voff[3]), "v"(voff[4]), "v"(voff[5]) : "memory");
+    if constexpr (AUX == 2) { ARTMIPS_GLDS_BODY(" nt") } else { ARTMIPS_GLDS_BODY("") }
+#undef ARTMIPS_GLDS_BODY
+}
+// one piece of a group on its own (the refill that rides between the MFMA chunks, mg_dma_after_chunk):
+// I = index of the piece inside its group, voff = its biased lane offset, dst = its LDS destination
+template <int AUX, int I>
+__device__ __forceinline__ void glds16_piece(const void* base, uint32_t voff, uint32_t dst) {
+    static_assert(AUX == 0 || AUX == 2, "asm DMA path knows the default and the nt policy");
+    static_assert(I >= 0 && I < 6, "piece index inside a group");
+    constexpr int OFF = I * 1024 - DMA_BIAS;
+    const uint32_t m0_val = dst - (uint32_t)OFF;
     uint32_t keep;
     if constexpr (AUX == 2)
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(base) : "memory");
+        asm volatile(ARTMIPS_GLDS_HEAD "global_load_lds_dwordx4 %3, %2 offset:%4 nt\n\t" ARTMIPS_GLDS_TAIL
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff), "n"(OFF) : "memory");
     else
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(base) : "memory");
+        asm volatile(ARTMIPS_GLDS_HEAD "global_load_lds_dwordx4 %3, %2 offset:%4\n\t" ARTMIPS_GLDS_TAIL
+                     : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff), "n"(OFF) : "memory");
+}
+// diagnostic build (ARTMIPS_ABLATE & 64): the pieces of a stage one by one, each with its own M0 round trip
+template <int AUX, int PPW, int GS, int PP>
+__device__ __forceinline__ void glds16_pieces(const void* base, const uint32_t* voff, uint32_t dst0) {
+    if constexpr (PP < PPW) {
+        glds16_piece<AUX, PP % GS>(base, voff[PP], dst0 + PP * 1024);
+        glds16_pieces<AUX, PPW, GS, PP + 1>(base, voff, dst0);
+    }
+}
+// pieces per M0 value for a wave that issues PPW pieces of a stage
+constexpr int dma_group_size(int ppw) { return ppw <= 4 ? ppw : (ppw % 6 == 0 ? 6 : (ppw % 4 == 0 ? 4 : (ppw % 3 == 0 ? 3 : 1))); }
+
+// Largest of four scores in two instructions.  fmaxf() costs five here: hipcc canonicalises two of the
+// inputs first (v_max x, x) because they come out of inline asm.  NaNs are ignored like fmaxf ignores
+// them (MFMA results are never signalling), which is all the filter's pre-check needs: some element
+// >= thr implies max4 >= thr.
+__device__ __forceinline__ float max4(const f32x4& v) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v[3]));
+    return m;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -293,11 +359,12 @@ __device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
     if constexpr (PP < PPW) {
         constexpr int SPAN = (NW == 8) ? NCH / 2 : NCH;
         constexpr int AT = (PP * SPAN) / PPW;          // chunk (inside the span) after which piece PP goes
+        constexpr int GI = PP % dma_group_size(PPW);   // index of the piece inside its group (lane_off is biased for it)
         if constexpr (NW == 8) {
-            if constexpr (C == AT) { if (d.on && !d.late) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
-            if constexpr (C == AT + SPAN) { if (d.on && d.late) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+            if constexpr (C == AT) { if (d.on && !d.late) glds16_piece<AUX, GI>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+            if constexpr (C == AT + SPAN) { if (d.on && d.late) glds16_piece<AUX, GI>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
         } else {
-            if constexpr (C == AT) { if (d.on) glds16_saddr<AUX>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
+            if constexpr (C == AT) { if (d.on) glds16_piece<AUX, GI>(d.tile, d.lane_off[PP], d.dst0 + PP * 1024); }
         }
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, PP + 1>(d);
     }
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-        thr[j] = (MODE == MODE_FILTER) ? (ablate ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
+        thr[j] = (MODE == MODE_FILTER) ? ((ablate & 63) ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
     // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image
@@ -481,38 +548,83 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const long long n_work = a.n_work;
     const long long stride = a.tile_stride;
     const long long n_it = (b < n_work) ? (n_work - b + grid - 1) / grid : 0;
-    const long long last_work = n_work - 1;
-    // work index -> tile (see ScanArgs::tile_skip; tile counts fit 32 bits: n_rows < 2^31)
-    auto tile_of = [&](long long wk) __attribute__((always_inline)) -> long long {
-        if (a.tile_skip) {
-            const uint32_t w32 = (uint32_t)wk;
-            return (a.tile_skip == 8) ? (long long)((w32 / 7u) * 8u + w32 % 7u + 1u)
-                                      : (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
-        }
-        return wk * stride;
+    // Work index -> tile (ScanArgs::tile_skip; tile counts fit 32 bits: n_rows < 2^31): with P = tile_skip,
+    // wk -> (wk / (P-1)) * P + wk % (P-1) + 1, otherwise wk * stride.  This workgroup visits the work
+    // indices b, b + grid, ... in order, so the tile is kept as a running (quotient, remainder) pair
+    // that one add, one compare and two selects advance: no division and no branch in the streaming
+    // loop (a single wave per SIMD pays for every scalar instruction between its MFMAs).
+    const uint32_t t_mod = a.tile_skip ? (uint32_t)a.tile_skip - 1u : 1u;
+    const uint32_t t_mult = a.tile_skip ? (uint32_t)a.tile_skip : (uint32_t)stride;
+    const uint32_t t_add = a.tile_skip ? 1u : 0u;
+    // (tile_skip is 0, 4 or 8: divisions by constants stay on the scalar unit, a division by a run-time
+    // value would be expanded on the vector unit; readfirstlane tells hipcc the results are uniform)
+    auto div_mod = [&](uint32_t x, uint32_t* rem) __attribute__((always_inline)) -> uint32_t {
+        uint32_t qq = x, rr = 0;
+        if (a.tile_skip == 8) { qq = x / 7u; rr = x % 7u; }
+        else if (a.tile_skip) { qq = x / 3u; rr = x % 3u; }
+        *rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)qq);
     };
+    uint32_t t_dr, t_r0;
+    const uint32_t t_dq = div_mod((uint32_t)grid, &t_dr);
+    const uint32_t t_q0 = div_mod((uint32_t)b, &t_r0);
+    struct TileWalk {
+        uint32_t q, r;
+        uint32_t left;    // work items of this workgroup from the current one on (>= 1 while it has any)
+    };
+    auto walk_begin = [&]() __attribute__((always_inline)) -> TileWalk {
+        // (n_it comes out of a 64-bit division that hipcc expands on the vector unit)
+        return TileWalk{t_q0, t_r0, (uint32_t)__builtin_amdgcn_readfirstlane((int)n_it)};
+    };
+    // the current tile, then one step on; past the workgroup's last item the walk stays on it (the
+    // ring's tail refills re-read that tile: any valid address keeps the vmcnt arithmetic uniform)
+    auto walk_next = [&](TileWalk& t) __attribute__((always_inline)) -> long long {
+        // (readfirstlane: the DMA takes its base from scalar registers, and hipcc must not move this
+        // chain of uniform values to the vector unit)
+        const long long tile = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(t.q * t_mult + t.r + t_add));
+        const bool more = t.left > 1;
+        uint32_t nr = t.r + t_dr;
+        const uint32_t carry = nr >= t_mod ? 1u : 0u;
+        nr -= carry ? t_mod : 0u;
+        t.r = more ? nr : t.r;
+        t.q = more ? t.q + t_dq + carry : t.q;
+        t.left -= more ? 1u : 0u;
+        return tile;
+    };
+    TileWalk walk_issue = walk_begin();   // stages are issued in order: prologue, then one per iteration
+    TileWalk walk_filter = walk_begin();  // and filtered in order, once each
 
     // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
     // (DMA side): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
+    // (biased for the grouped DMA issue: piece pp is the (pp % GS)-th of its group, see glds16_group)
+    constexpr int GS = dma_group_size(PPW);
+    static_assert(PPW % GS == 0, "pieces must split evenly into DMA groups");
     uint32_t lane_off[PPW];
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
         const int pos = (w * PPW + pp) * 64 + lane;
         const int trow = pos / CPR;
-        lane_off[pp] = (uint32_t)(trow * ROWB + (((pos - trow * CPR) ^ (trow & 15)) * 16));
+        lane_off[pp] = (uint32_t)(trow * ROWB + (((pos - trow * CPR) ^ (trow & 15)) * 16))
+                       + (uint32_t)(DMA_BIAS - (pp % GS) * 1024);
     }
 
     // The shard's row buffer is allocated in whole tiles (artmips_begin pads it with zero rows), so a
     // DMA never needs a per-lane clamp: uniform tile base + per-lane constant.  Rows past n_rows are
     // scored like any other and dropped by the `row < n_rows` test of the filter.
-    auto issue_stage = [&](long long it, int slot) __attribute__((always_inline)) {
-        long long wk = b + it * grid;
-        if (wk > last_work) wk = last_work;  // keep the vmcnt arithmetic uniform past the end
-        const long long row0 = tile_of(wk) * TILE_ROWS;
+    int fill_slot = 0;   // ring slot the next issued stage goes to
+    auto issue_stage = [&]() __attribute__((always_inline)) {
+        const long long row0 = walk_next(walk_issue) * TILE_ROWS;
         const char* tile = (const char*)rows + row0 * ROWB;
-        const uint32_t dst0 = lds_base + (uint32_t)(slot * STAGE_BYTES + w * PPW * 1024);
+        const uint32_t dst0 = lds_base + (uint32_t)(fill_slot * STAGE_BYTES + w * PPW * 1024);
+        // (the HBM-bound one-group kernel is 0.3 % faster with the pieces spaced by their scalar
+        // instructions than with the burst: profiles/r03_a_gang_ab.txt)
+        if (!ASM_PATH || (ablate & 64)) {
+            glds16_pieces<AUX, PPW, GS, 0>(tile, lane_off, dst0);
+            return;
+        }
 #pragma unroll
-        for (int pp = 0; pp < PPW; ++pp) glds16_saddr<AUX>(tile, lane_off[pp], dst0 + pp * 1024);
+        for (int gi = 0; gi < PPW / GS; ++gi)
+            glds16_group<AUX, GS>(tile, &lane_off[gi * GS], dst0 + (uint32_t)(gi * GS * 1024 + DMA_BIAS));
     };
 
     static_assert(TOPT == 1 || MODE == MODE_GROUPMAX, "TOPT belongs to pass 0");
@@ -546,8 +658,17 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // Filter (or pass-0 maxima) of one finished stage: acc[j][i] = score(row = tile*16 + g*4 + i,
     // query = j*QG + w*16 + r)
     f32x4 acc[NQ];   // multi-group path: lives across iterations (its filter runs one stage late)
-    auto epilogue = [&](long long it_e, f32x4* acc) __attribute__((always_inline)) {
-        const long long row_base = tile_of(b + it_e * grid) * TILE_ROWS + g * 4;
+    auto epilogue = [&](f32x4* acc) __attribute__((always_inline)) {
+        const long long row_base = walk_next(walk_filter) * TILE_ROWS + g * 4;
+        if constexpr (MODE == MODE_FILTER && NQ > 1) {
+            // the common case (no survivor in any column group of this wave) leaves through ONE branch
+            if (!(ablate & (16 | 256))) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) any |= max4(acc[j]) >= thr[j];
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (ablate & 16) {
@@ -590,7 +711,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     if (n_it > 0) {
         // prologue: NSTAGE-1 stages in flight, issued while the query operand is still on its way
 #pragma unroll
-        for (int s = 0; s < NSTAGE - 1; ++s) issue_stage(s, s);
+        for (int s = 0; s < NSTAGE - 1; ++s) {
+            issue_stage();
+            ++fill_slot;
+        }
         // Drain the operand loads (and with them the prologue, whose latency they share) before the
         // streaming loop, so that hipcc never has a reason to put a vmcnt(0) inside it (the asm loads
         // into AGPRs are not counted by hipcc at all).  The ring refills from iteration 0 on.
@@ -600,7 +724,6 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
 
         int slot = 0;
-        int fill_slot = NSTAGE - 1;
         for (long long it = 0; it < n_it; ++it) {
             // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
             wait_vmcnt<(NSTAGE - 2) * PPW>();
@@ -613,16 +736,20 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             dma.noread = (ablate & 8) != 0;
             dma.nowait = (ablate & 32) != 0;
             if constexpr (ASM_PATH && INLINE_DMA) {
-                long long wk = b + (it + NSTAGE - 1) * grid;
-                if (wk > last_work) wk = last_work;
-                const long long row0 = tile_of(wk) * TILE_ROWS;
                 dma.on = wave_active && !(ablate & 1);
+                // (an idle wave, or the diagnostic build without the refill, issues through issue_stage or
+                // not at all: the walk advances exactly once per iteration either way)
+                const long long row0 = dma.on ? walk_next(walk_issue) * TILE_ROWS : 0;
                 dma.tile = (const char*)rows + row0 * ROWB;
                 dma.lane_off = lane_off;
                 dma.dst0 = lds_base + (uint32_t)(fill_slot * STAGE_BYTES + w * PPW * 1024);
                 dma.late = (w >= NW / 2);
             }
-            if (!dma.on && !(ablate & 1)) issue_stage(it + NSTAGE - 1, fill_slot);
+            // (tried in round 3 and dropped, profiles/r03_a_gang_ab.txt: the burst BEHIND the stage's MFMAs
+            // instead of in front of them, -0.7 % on one box and +2.9 % on another; and the first row
+            // fragments of a stage requested before its wait and barrier, with one stage less of
+            // look-ahead: +-0.5 % in the gang shapes)
+            if (!dma.on && !(ablate & 1)) issue_stage();
             fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
 
             if (wave_active) {
@@ -653,7 +780,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                         __builtin_amdgcn_sched_group_barrier(0x100, CHB, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, CHB * NQ * MPF, 0);
                     }
-                    epilogue(it, acc);
+                    epilogue(acc);
                 } else {
                     // chunks of CH k-steps, row fragments double-buffered in registers; the filter of
                     // the PREVIOUS stage runs inside, behind the first LDS read requests (mg_compute)
@@ -664,7 +791,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                     auto pre = [&]() __attribute__((always_inline)) {
                         if (it > 0) {
                             mg_settle_short<NQ, 0>(acc);
-                            epilogue(it - 1, acc);
+                            epilogue(acc);
                         }
                     };
                     mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma, pre);
@@ -675,7 +802,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         if constexpr (NQ > 1) {
             if (wave_active) {   // the last stage's filter (every other stage's ran inside the next one)
                 mg_settle<NQ, 0>(acc);
-                epilogue(n_it - 1, acc);
+                epilogue(acc);
             }
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
@@ -1015,11 +1142,17 @@ __device__ void topk_finish(u64* keys, int M, bool in_lds, const int32_t* row_id
         __syncthreads();
         SEL_PHASE(sc.stop, 4);
         if (got <= RANK_MAX) {
-            // keys are distinct: the number of larger keys is the output position
+            // the number of keys in front of a key is its output position.  Keys of a well-formed index
+            // are distinct (unique passage ids); equal keys (a caller's duplicate ids, or a merge fed the
+            // same list twice) are ordered by survivor slot, so that the ranks stay a permutation and no
+            // output slot is left unwritten
             for (int i = tid; i < got; i += blockDim.x) {
                 const u64 key = sc.sub[i];
                 int rank = 0;
-                for (int j = 0; j < got; ++j) rank += (sc.sub[j] > key);
+                for (int j = 0; j < got; ++j) {
+                    const u64 other = sc.sub[j];
+                    rank += (other > key) || (other == key && j < i);
+                }
                 if (rank < k) {
                     store_score(o.scores, o.score_dtype, o.row * (long long)k + rank, key_score(key));
                     o.ids[o.row * (long long)k + rank] = key_id(key);

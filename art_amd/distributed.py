@@ -76,7 +76,9 @@ class SpmdSearcher(object):
     the merge hides behind the scan.  If some rank's candidate lists overflowed (rare: the lists
     are sized 8x the expectation) every rank sees it in the flag, grows its lists and repeats the
     step, so the ranks never disagree about the number of collectives.
-    Buffers are cached per (Q, k): the steady state allocates only the two result tensors."""
+    Buffers are cached per (Q, k): the steady state allocates only the two result tensors.
+    `engine` is a MipsEngine, or anything with its search_local_async / merge_packed_sync / grow_lists
+    (the CPU tests of the collective protocol drive a stand-in that injects overflow flags)."""
 
     def __init__(self, engine, group=None, always_gather=False, chunk_queries=2048):
         if chunk_queries < 256 or chunk_queries % 256:
@@ -107,8 +109,6 @@ class SpmdSearcher(object):
         return b
 
     def search(self, queries, top_k, score_dtype=torch.float16):
-        from .engine import MipsEngine
-
         if self._world is None:  # the group does not change under a searcher: ask once
             self._world = dist.get_world_size(self.group) if dist.is_initialized() else 1
             self._nccl = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
@@ -124,7 +124,7 @@ class SpmdSearcher(object):
                 self._all_gather(gathered, local)
             # the step's only host wait: the merge writes the flag into a pinned host word and the
             # stream is synchronised inside the call (no device-to-host copy behind the merge)
-            s, i, status = MipsEngine.merge_packed_sync(gathered, n_q, top_k, score_dtype)
+            s, i, status = self.engine.merge_packed_sync(gathered, n_q, top_k, score_dtype)
             if status & 2:
                 raise RuntimeError("artmips: internal key scratch too small on some rank")
             if not (status & 1):
@@ -171,14 +171,15 @@ class SpmdSearcher(object):
             for (q0, q1), (local, gathered), work in zip(bounds, bufs, works):
                 if work is not None:
                     work.wait()  # the search stream waits for the collective; the host does not
-                s, i, st = MipsEngine.merge_packed_sync(gathered, q1 - q0, top_k, score_dtype)
+                s, i, st = self.engine.merge_packed_sync(gathered, q1 - q0, top_k, score_dtype)
                 out_s[q0:q1] = s
                 out_i[q0:q1] = i
                 status |= st
             if status & 2:
                 raise RuntimeError("artmips: internal key scratch too small on some rank")
             if not (status & 1):
-                torch.cuda.current_stream(dev).synchronize()
+                if dev.type == "cuda":
+                    torch.cuda.current_stream(dev).synchronize()
                 return out_s, out_i
             self.engine.grow_lists()
             self.last_retries += 1

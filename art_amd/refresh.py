@@ -12,7 +12,7 @@ Two sinks with the store's ``add_block_data(row_id, block_embeds)`` signature:
 
   DeviceIndexWriter   one process owns every shard (the reference's process model)
   SpmdIndexWriter     one process per GPU, each owning the rows [lo, hi) of the id range; batches
-                      are exchanged by owner with all_to_all at commit time
+                      are exchanged by owner with all_to_all in rounds, while the encoder runs
 """
 import numpy as np
 import torch
@@ -108,18 +108,36 @@ def route_by_owner(row_id, block_embeds, n_rows, id_base, world):
     return row_id[order], block_embeds[order], counts
 
 
+_DTYPE_CODES = [torch.float16, torch.bfloat16, torch.float32]
+
+
 class SpmdIndexWriter(object):
     """One process per GPU: this rank's engine (one shard) receives the rows whose position
     id - id_base falls in its torch.chunk range; everything else is sent to its owner.
 
-    add_block_data() only buffers (on the device, in the encoder's dtype); commit() is
-    collective: an all_to_all of the row counts, one of the ids, one of the rows (RCCL over xGMI
-    with the "nccl" backend), a scatter into the local shard, and the swap.
+    STREAMING: add_block_data() buffers on the device (in the encoder's dtype) and, whenever
+    `flush_bytes` have accumulated, runs one exchange ROUND: an all_to_all of the per-destination row
+    counts (one small message that also carries each rank's "I am committing" flag), then all_to_alls
+    of the ids and of the rows (RCCL over xGMI with the "nccl" backend), asynchronous: the transfer of
+    round f runs on RCCL's stream beside whatever the encoder enqueues for round f+1, and its rows are
+    scattered into the local shard when round f+1 starts (or at commit).  A rank therefore holds at
+    most the batch it is accumulating plus one round in flight, not its whole output (the reference
+    side this replaces keeps everything in a dict until the end and moves it through the filesystem:
+    indexer.py:146-165).  With the reference's sampler consecutive ids are encoded at the same time
+    (samplers.py:142-148), so at any moment ALL ranks send to the same owner: that owner receives up to
+    world x flush_bytes per round.
+
+    Rounds are rendezvous, so all ranks run the same number of them whatever their batch counts and
+    sizes: a rank triggers a round when its buffer is full; commit() keeps running rounds with the
+    flag set until a round in which every rank had it set.  A rank that finished early simply serves
+    the others' rounds from inside commit().  Duplicate and missing rows are detected by the engine
+    over the whole generation (scatter atomics + the count at finalize), across all rounds.
+
     `sink(rows, ids, id_base_local)` defaults to engine.upload_scatter and exists so that the
     exchange can be tested on the CPU with gloo.
     """
 
-    def __init__(self, engine, n_rows, id_base=1, group=None, sink=None, device=None):
+    def __init__(self, engine, n_rows, id_base=1, group=None, sink=None, device=None, flush_bytes=64 << 20):
         self.engine = engine
         self.n_rows = int(n_rows)
         self.id_base = int(id_base)
@@ -131,23 +149,56 @@ class SpmdIndexWriter(object):
             device = torch.device("cuda", engine.devices[0])
         self.device = device
         self._sink = sink if sink is not None else engine.upload_scatter
+        self.flush_bytes = int(flush_bytes)
         self._ids, self._rows = [], []
+        self._acc_bytes = 0          # bytes in the batch being accumulated
+        self._pending = None         # the round in flight: (works, ids_in, rows_in, keep-alive, bytes)
+        self._dim = engine.dim if engine is not None else None
+        self.rounds = 0              # exchange rounds run so far (identical on every rank)
+        self.rows_received = 0
+        self.peak_buffered_bytes = 0  # accumulating batch + round in flight, the most this rank ever held
+        self._nccl = self.world > 1 and dist.get_backend(group) == "nccl"
         if engine is not None:
             engine.begin(self.hi - self.lo)
+
+    def _note_peak(self):
+        held = self._acc_bytes + (self._pending[4] if self._pending is not None else 0)
+        if held > self.peak_buffered_bytes:
+            self.peak_buffered_bytes = held
 
     def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
         if allow_overwrite:
             raise ValueError("allow_overwrite is not supported by the device refresh path")
         if self.device.type == "cuda":
             row_id, block_embeds = _as_cuda(row_id, block_embeds, self.device)
-        self._ids.append(row_id.reshape(-1).to(torch.int64))
+        row_id = row_id.reshape(-1).to(torch.int64)
+        self._ids.append(row_id)
         self._rows.append(block_embeds)
+        if self._dim is None:
+            self._dim = int(block_embeds.shape[1])
+        self._acc_bytes += block_embeds.numel() * block_embeds.element_size() + row_id.numel() * 8
+        self._note_peak()
+        if self._acc_bytes >= self.flush_bytes:
+            self._round(final=False)
 
-    def commit(self, save_flat=None):
-        """Collective.  save_flat: path of ONE flat store file that every rank writes its shard into
-        (flat_store.save_engine_flat_shared) once the new generation is live: the on-disk artefact the
-        reference's indexer leaves at --embedding-path (indexer.py:156-163)."""
-        dim = self.engine.dim if self.engine is not None else (self._rows[0].shape[1] if self._rows else 0)
+    def _drain(self):
+        """Finish the round in flight: wait for its transfer (the current stream waits, not the host,
+        under "nccl") and scatter what arrived into the local shard."""
+        if self._pending is None:
+            return
+        works, ids_in, rows_in, _keep, _bytes = self._pending
+        for w in works:
+            if w is not None:
+                w.wait()
+        self._pending = None
+        if ids_in.numel():
+            ids_in, rows_in = ids_in.to(self.device), rows_in.to(self.device)
+            self._sink(rows_in, ids_in, self.id_base + self.lo)
+            self.rows_received += int(ids_in.numel())
+
+    def _round(self, final):
+        """One exchange round (collective).  Returns True when every rank passed final=True."""
+        dim = self._dim if self._dim is not None else 0
         if self._ids:
             ids = torch.cat(self._ids)
             rows = torch.cat(self._rows)
@@ -156,22 +207,52 @@ class SpmdIndexWriter(object):
             rows = torch.empty((0, dim), dtype=torch.float16, device=self.device)
         self._ids, self._rows = [], []
         ids, rows, send = route_by_owner(ids, rows, self.n_rows, self.id_base, self.world)
+        all_final = bool(final)
         if self.world > 1:
             # "nccl" (RCCL) exchanges device buffers directly; gloo (CPU tests, or two ranks sharing
-            # one GPU in the test-suite) goes through host copies
-            xdev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            # one GPU in the test-suite) goes through host copies and runs synchronously
+            xdev = self.device if self._nccl else torch.device("cpu")
             ids, rows = ids.to(xdev), rows.contiguous().to(xdev)
-            send_t = torch.tensor(send, dtype=torch.int64, device=xdev)
-            recv_t = torch.empty_like(send_t)
-            dist.all_to_all_single(recv_t, send_t, group=self.group)
-            recv = recv_t.tolist()
+            dcode = _DTYPE_CODES.index(rows.dtype)
+            meta = torch.tensor([[c, 1 if final else 0, rows.shape[1], dcode] for c in send], dtype=torch.int64,
+                                device=xdev)
+            meta_in = torch.empty_like(meta)
+            dist.all_to_all_single(meta_in, meta, group=self.group)
+            m = meta_in.tolist()
+            recv = [int(x[0]) for x in m]
+            all_final = all(int(x[1]) for x in m)
+            # a rank with nothing to send learns the row width and dtype from the peers that send to it
+            # (all ranks encode with one model: the senders agree)
+            senders = [x for x in m if int(x[0]) > 0]
+            if rows.shape[0] == 0 and senders:
+                rows = torch.empty((0, int(senders[0][2])), dtype=_DTYPE_CODES[int(senders[0][3])], device=xdev)
+            width = rows.shape[1]
             ids_in = torch.empty(sum(recv), dtype=torch.int64, device=xdev)
-            dist.all_to_all_single(ids_in, ids, recv, send, group=self.group)
-            rows_in = torch.empty((sum(recv), rows.shape[1]), dtype=rows.dtype, device=xdev)
-            dist.all_to_all_single(rows_in, rows, recv, send, group=self.group)
-            ids, rows = ids_in.to(self.device), rows_in.to(self.device)
-        if ids.numel():
-            self._sink(rows, ids, self.id_base + self.lo)
+            rows_in = torch.empty((sum(recv), width), dtype=rows.dtype, device=xdev)
+            w1 = dist.all_to_all_single(ids_in, ids, recv, send, group=self.group, async_op=self._nccl)
+            w2 = dist.all_to_all_single(rows_in, rows, recv, send, group=self.group, async_op=self._nccl)
+            # the previous round's transfer ran beside everything enqueued since: finish it now
+            self._drain()
+            nbytes = (rows.numel() + rows_in.numel()) * rows.element_size() + (ids.numel() + ids_in.numel()) * 8
+            self._pending = ((w1, w2), ids_in, rows_in, (ids, rows), nbytes)
+        else:
+            self._drain()
+            self._pending = ((), ids, rows, None, 0)
+        self._acc_bytes = 0
+        self._note_peak()
+        self.rounds += 1
+        if self.world == 1:
+            self._drain()
+        return all_final
+
+    def commit(self, save_flat=None):
+        """Collective.  Runs exchange rounds until every rank is committing, scatters what is still in
+        flight, and swaps the new generation in.  save_flat: path of ONE flat store file that every rank
+        writes its shard into (flat_store.save_engine_flat_shared) once the new generation is live: the
+        on-disk artefact the reference's indexer leaves at --embedding-path (indexer.py:156-163)."""
+        while not self._round(final=True):
+            pass
+        self._drain()
         if self.engine is not None:
             _finalize(self.engine)
             if save_flat:
@@ -179,7 +260,7 @@ class SpmdIndexWriter(object):
 
                 barrier = (lambda: dist.barrier(group=self.group)) if self.world > 1 else (lambda: None)
                 save_engine_flat_shared(self.engine, save_flat, self.lo, self.n_rows, self.rank, barrier)
-        return int(ids.numel())
+        return self.rows_received
 
 
 __all__ = ["DeviceIndexWriter", "SpmdIndexWriter", "route_by_owner"]

@@ -29,6 +29,7 @@ DIM = 768
 HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
 STAT_EVERY = 4  # steps between two HIP-event timings of the scan kernel
 PREWARM_STEPS = 16  # untimed steps after the idle settle window (clock ramp), before the W warm-up steps
+FIRST_STEPS = 5  # of which the first few are timed individually (value_first_steps: no conditioning)
 
 
 def parse():
@@ -200,8 +201,19 @@ def main():
     # The idle window leaves the GPU in its low-power state and the first ~10 launches after it run up
     # to 25 % slower while the clocks ramp (profiles/r01_q_README.txt): PREWARM_STEPS untimed steps
     # bring it back to the state a training loop keeps it in, then the W warm-up steps follow.
-    for _ in range(PREWARM_STEPS):
-        step()
+    # The first FIRST_STEPS of them are timed one by one (each ends with the call's own synchronise) and
+    # reported as `value_first_steps`: the unconditioned figure, what a loop that searches once in a
+    # while sees right after an idle period.  `value` stays the steady-state contract figure.
+    first_ms = []
+    for i in range(PREWARM_STEPS):
+        if i < FIRST_STEPS:
+            torch.cuda.synchronize()
+            t_first = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            first_ms.append((time.perf_counter() - t_first) * 1e3)
+        else:
+            step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -267,6 +279,12 @@ def main():
             "prewarm_steps": PREWARM_STEPS,
             "settle_seconds": args.settle_seconds,
             "ms_per_step": ms_per_step,
+            "value_first_steps": args.queries * len(first_ms) / (sum(first_ms) * 1e-3),
+            "first_steps_ms": [round(x, 4) for x in first_ms],
+            "ranks": {"dist_world_size": dist.get_world_size() if spmd else 1,
+                      "dist_backend": dist.get_backend() if spmd else None,
+                      "cuda_device_count": torch.cuda.device_count(),
+                      "local_rank": local_rank},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -22,7 +22,11 @@
  *     artmips_search_local_noalloc, artmips_merge and artmips_merge_packed only enqueue and
  *     hand the status word to the caller instead.
  *   - rows are `dim` elements of the storage dtype, row-major, contiguous.
- *   - passage ids are int32 (the reference returns int32: art_index.py:297).
+ *   - passage ids are int32 (the reference returns int32: art_index.py:297) and must be UNIQUE
+ *     over the index, as the keys of the reference's dict are (art_index.py:56-61).  The scatter
+ *     upload detects a repeated id (artmips_finalize fails); artmips_upload / artmips_upload_device
+ *     do not look for them.  A repeated id does not break a search: rows that share an id and a
+ *     score are both returned, in unspecified relative order, and every output slot is written.
  *   - a handle is used by one thread at a time (the reference drives its index from one
  *     Python thread of one process per node: art_model.py:327,351), with one exception:
  *     artmips_download / artmips_generation may run on a second thread.  Different handles are

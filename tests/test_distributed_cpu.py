@@ -69,3 +69,104 @@ def test_shard_bounds_are_torch_chunk():
     assert shard_bounds(21015324, 8)[7] == (7 * 2626916, 21015324)
     assert shard_bounds(5, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     assert shard_bounds(1003, 4) == orc.shard_bounds(1003, 4)
+
+
+# ---- world 8: the collective protocol of SpmdSearcher (single exchange and pipelined chunks) with an
+# overflow flag injected on ONE rank in ONE chunk: every rank must repeat the step and issue the same
+# number of collectives (a rank that disagreed would hang the next all-gather on a real node)
+class _FakeEngine(object):
+    """Stands in for MipsEngine on the CPU: the oracle searches this rank's rows into the packed layout
+    [Q*k score bits | Q*k ids | 4 status words] (include/artmips.h); merge_packed_sync is the oracle's
+    merge plus the OR of the lists' status words, as merge_kernel does it."""
+
+    def __init__(self, rows, ids, overflow_on_call):
+        self.rows, self.ids = rows, ids
+        self.overflow_on_call = overflow_on_call  # index of the search_local_async call that overflows
+        self.calls = 0
+        self.grown = 0
+
+    def search_local_async(self, slot, queries, top_k, out_packed):
+        q = queries.numpy().astype(np.float64)
+        s, i, _ = orc.exact_topk(q, self.rows, self.ids, top_k)
+        pad = top_k - s.shape[1]
+        if pad > 0:
+            s = np.concatenate([s, np.full((s.shape[0], pad), -np.inf, np.float32)], 1)
+            i = np.concatenate([i, np.full((i.shape[0], pad), np.iinfo(np.int32).max, np.int32)], 1)
+        plane = q.shape[0] * top_k
+        out_packed[:plane] = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).view(torch.int32).reshape(-1)
+        out_packed[plane:2 * plane] = torch.from_numpy(np.ascontiguousarray(i, dtype=np.int32)).reshape(-1)
+        out_packed[2 * plane:] = 0
+        if self.calls == self.overflow_on_call and self.grown == 0:
+            out_packed[2 * plane] = 1
+        self.calls += 1
+
+    @staticmethod
+    def merge_packed_sync(packed, n_q, top_k, score_dtype=torch.float32):
+        plane = n_q * top_k
+        s = packed[:, :plane].contiguous().view(torch.float32).reshape(packed.shape[0], n_q, top_k).numpy()
+        i = packed[:, plane:2 * plane].reshape(packed.shape[0], n_q, top_k).numpy()
+        flag = 0
+        for g in range(packed.shape[0]):
+            flag |= int(packed[g, 2 * plane])
+        ms, mi = orc.merge_topk(s, i, top_k)
+        return torch.from_numpy(ms).to(score_dtype), torch.from_numpy(mi), flag
+
+    def grow_lists(self):
+        self.grown += 1
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd import distributed as D
+
+        rng = np.random.Generator(np.random.PCG64(808))
+        n, dim = 4000, 32
+        rows = rng.integers(-4, 5, size=(n, dim)).astype(np.float64)
+        ids = (rng.permutation(n) + 1).astype(np.int32)
+        lo, hi = shard_bounds(n, world)[rank]
+        gathers = [0]
+        real_all_gather = dist.all_gather
+
+        def counting_all_gather(*a, **kw):
+            gathers[0] += 1
+            return real_all_gather(*a, **kw)
+
+        dist.all_gather = counting_all_gather
+        report = {}
+        # (a) one exchange per step: 70 queries x top-12, rank 5 overflows on its first search
+        queries = rng.integers(-3, 4, size=(70, dim)).astype(np.float32)
+        eng = _FakeEngine(rows[lo:hi], ids[lo:hi], overflow_on_call=0 if rank == 5 else -1)
+        searcher = D.SpmdSearcher(eng)
+        s, i = searcher.search(torch.from_numpy(queries), 12, torch.float32)
+        want_s, want_i, _ = orc.exact_topk(queries.astype(np.float64), rows, ids, 12)
+        assert np.array_equal(i.numpy(), want_i) and np.array_equal(s.numpy(), want_s)
+        assert searcher.last_retries == 1 and eng.calls == 2 and eng.grown == 1
+        report["single"] = gathers[0]
+        # (b) pipelined: 700 queries in chunks of 256 (3 chunks), rank 2 overflows in chunk 1
+        gathers[0] = 0
+        queries = rng.integers(-3, 4, size=(700, dim)).astype(np.float32)
+        eng = _FakeEngine(rows[lo:hi], ids[lo:hi], overflow_on_call=1 if rank == 2 else -1)
+        searcher = D.SpmdSearcher(eng, chunk_queries=256)
+        s, i = searcher.search(torch.from_numpy(queries), 9, torch.float32)
+        want_s, want_i, _ = orc.exact_topk(queries.astype(np.float64), rows, ids, 9)
+        assert np.array_equal(i.numpy(), want_i) and np.array_equal(s.numpy(), want_s)
+        assert searcher.last_retries == 1 and eng.calls == 6 and eng.grown == 1
+        report["pipelined"] = gathers[0]
+        with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+            f.write("%d %d" % (report["single"], report["pipelined"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spmd_searcher_world8_overflow_on_one_rank_keeps_collectives_in_step(tmp_path):
+    world = 8
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    counts = [open(tmp_path / ("r%d.txt" % r)).read().split() for r in range(world)]
+    # every rank: 2 all-gathers for the single-exchange step (first try + the repeat), 6 for the three
+    # chunks (3 + 3); identical on all ranks
+    assert all(c == ["2", "6"] for c in counts), counts

@@ -60,3 +60,30 @@ def test_restatement_is_the_reference(fx, fam):
         d, i = orc.reference_restatement(queries, rows, ids, k, n_shards=g)
         assert np.array_equal(d.numpy(), ref_dist)
         assert np.array_equal(i.numpy(), ref_idx)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/megatron/data/art_index.py"),
+                    reason="the reference is only present in the build container")
+def test_committed_fixture_is_what_the_reference_produces(fx, golden_dir):
+    """Guard of the pin itself: re-run the reference's own add_embed_data + search_mips_index
+    (tests/golden/make_golden_ref_search.py, device placement redirected to the CPU) on the inputs stored
+    in fx_ref_search.npz and require the stored outputs, for every (family, shards, k) case."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden_ref_search",
+                                                  os.path.join(golden_dir, "make_golden_ref_search.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    ref = gen.load_reference()
+    cases = 0
+    for fam in ("int", "rnd"):
+        rows, queries, ids = fx[fam + "_rows"], fx[fam + "_queries"], fx[fam + "_ids"]
+        for g, k, want_dist, want_idx in _cases(fx, fam):
+            dist, idx, chunks = gen.run_reference(ref, rows, ids, queries, k, g)
+            assert np.array_equal(dist.view(np.uint16), want_dist.view(np.uint16)), (fam, g, k)
+            assert np.array_equal(idx, want_idx), (fam, g, k)
+            key = "%s_g%d_chunks" % (fam, g)
+            if key in fx.files:
+                assert list(chunks) == fx[key].tolist()
+            cases += 1
+    assert cases == 13

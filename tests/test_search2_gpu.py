@@ -284,6 +284,7 @@ eng.close()
 print("staging ok")
 ''' % ROOT
     env = dict(os.environ)
+    env["ARTMIPS_DIAGNOSTICS"] = "1"
     env["ARTMIPS_LIBRARY"] = os.path.join(ROOT, "art_amd", "lib", "libartmips_diag.so")
     env["ARTMIPS_FORCE_STAGING"] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-ablate_pmc}
 mkdir -p $O
+export ARTMIPS_DIAGNOSTICS=1
 export ARTMIPS_LIBRARY=$R/art_amd/lib/libartmips_diag.so
 dirs=""
 for A in ${2:-0 1 8 16 24 27}; do

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Why does the same scan run 4.5 ms in one process and 4.8 ms in the next?  One measurement per
 invocation: build the 21M-row index, time the FILTER scan and a plain device copy.
-box_state_test.py TAG [prealloc_gb]"""
+box_state_probe.py TAG [prealloc_gb]"""
 import os
 import sys
 import time

@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the ARTMIPS_* knobs this script turns exist only in the diagnostic build of the library
+os.environ.setdefault("ARTMIPS_DIAGNOSTICS", "1")
 os.environ.setdefault("ARTMIPS_LIBRARY", os.path.join(ROOT, "art_amd", "lib", "libartmips_diag.so"))
 import bench  # noqa: E402
 from art_amd.engine import MipsEngine  # noqa: E402

@@ -1,5 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export ARTMIPS_DIAGNOSTICS=1
 export ARTMIPS_LIBRARY=$R/art_amd/lib/libartmips_diag.so  # the knobs below exist only in the diagnostic build
 for cfg in "4 4 0" "4 4 1" "4 4 4" "8 2 0" "8 2 1"; do
   set -- $cfg

@@ -10,6 +10,7 @@ import torch
 
 R = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
+os.environ.setdefault("ARTMIPS_DIAGNOSTICS", "1")
 os.environ.setdefault("ARTMIPS_LIBRARY", R + "/art_amd/lib/libartmips_diag.so")   # (another diagnostic build may be named)
 import bench  # noqa: E402
 from art_amd.engine import MipsEngine  # noqa: E402

@@ -1,6 +1,7 @@
 # Step time against the pass-0 sample divisor (diagnostic build, ARTMIPS_SAMPLE_DIV) on one shard size.
 # usage: bash tools/sample_div_sweep.sh ROWS "DIV DIV ..." [steps] [topk] [queries]   (DIV 0 = the fitted value)
 R=$GRAFT_REPO_ROOT
+export ARTMIPS_DIAGNOSTICS=1
 export ARTMIPS_LIBRARY=$R/art_amd/lib/libartmips_diag.so
 for rep in 1 2; do
 for D in $2; do

@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT
 ROWS=${1:-2626916}
 O=$R/gpurun_out/${2:-select_phases}
 mkdir -p $O
+export ARTMIPS_DIAGNOSTICS=1
 export ARTMIPS_LIBRARY=$R/art_amd/lib/libartmips_diag.so
 for S in ${3:-1 2 6 3 4 5 7 0}; do
   export ARTMIPS_SELECT_STOP=$S
