@@ -51,13 +51,13 @@ struct arttok {
 // One wave (64 lanes) per output row; rows are grid-strided.  Lanes read consecutive tokens of the
 // item (coalesced) and write consecutive int32 of the padded row.
 template <typename E>
-__global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict__ tokens,
-                                                            const int64_t* __restrict__ offsets,
-                                                            const int32_t* __restrict__ sizes,
-                                                            int64_t n_items, const int32_t* __restrict__ ids,
-                                                            int64_t n, int32_t id_base, int max_len,
-                                                            int32_t pad, int32_t* __restrict__ out_tokens,
-                                                            int32_t* __restrict__ out_lens) {
+__device__ __forceinline__ void gather_tokens_body(const E* __restrict__ tokens,
+                                                   const int64_t* __restrict__ offsets,
+                                                   const int32_t* __restrict__ sizes,
+                                                   int64_t n_items, const int32_t* __restrict__ ids,
+                                                   int64_t n, int32_t id_base, int max_len,
+                                                   int32_t pad, int32_t* __restrict__ out_tokens,
+                                                   int32_t* __restrict__ out_lens) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -74,6 +74,16 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict_
         if (lane == 0) out_lens[i] = len;
     }
 }
+template <typename E>
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict__ tokens,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ sizes,
+                                                            int64_t n_items, const int32_t* __restrict__ ids,
+                                                            int64_t n, int32_t id_base, int max_len,
+                                                            int32_t pad, int32_t* __restrict__ out_tokens,
+                                                            int32_t* __restrict__ out_lens) {
+    gather_tokens_body<E>(tokens, offsets, sizes, n_items, ids, n, id_base, max_len, pad, out_tokens, out_lens);
+}
 
 // The same gather with 16-byte stores: every lane takes 4 consecutive tokens of an item (its four loads
 // are independent and the lanes' loads cover one contiguous run of the token file) and writes one int4
@@ -85,13 +95,13 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const E* __restrict_
 // Needs 16-byte aligned output rows (max_len % 4 == 0, aligned base); the host falls back to
 // gather_tokens_kernel otherwise.
 template <typename E>
-__global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restrict__ tokens,
-                                                                const int64_t* __restrict__ offsets,
-                                                                const int32_t* __restrict__ sizes,
-                                                                int64_t n_items, const int32_t* __restrict__ ids,
-                                                                int64_t n, int32_t id_base, int max_len,
-                                                                int32_t pad, int32_t* __restrict__ out_tokens,
-                                                                int32_t* __restrict__ out_lens, int lpi) {
+__device__ __forceinline__ void gather_tokens_vec_body(const E* __restrict__ tokens,
+                                                       const int64_t* __restrict__ offsets,
+                                                       const int32_t* __restrict__ sizes,
+                                                       int64_t n_items, const int32_t* __restrict__ ids,
+                                                       int64_t n, int32_t id_base, int max_len,
+                                                       int32_t pad, int32_t* __restrict__ out_tokens,
+                                                       int32_t* __restrict__ out_lens, int lpi) {
     const int lane = threadIdx.x & 63;
     const int sub = lane / lpi, sl = lane - sub * lpi;   // item slot of this lane in the wave, lane in the item
     const int ipw = 64 / lpi;                            // items per wave and group
@@ -132,6 +142,58 @@ __global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restr
             if (sl == 0) out_lens[idx[u]] = len[u];
         }
     }
+}
+template <typename E>
+__global__ __launch_bounds__(256) void gather_tokens_vec_kernel(const E* __restrict__ tokens,
+                                                                const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ sizes,
+                                                                int64_t n_items, const int32_t* __restrict__ ids,
+                                                                int64_t n, int32_t id_base, int max_len,
+                                                                int32_t pad, int32_t* __restrict__ out_tokens,
+                                                                int32_t* __restrict__ out_lens, int lpi) {
+    gather_tokens_vec_body<E>(tokens, offsets, sizes, n_items, ids, n, id_base, max_len, pad, out_tokens,
+                              out_lens, lpi);
+}
+
+// Several datasets, one launch (the four token datasets a training step fetches for the same [Q, k]
+// winners: art_model.py:367-381).  blockIdx.y picks the dataset; its workgroups run the single-dataset
+// body, so the four dependent-load chains (id -> size and offset -> tokens) of an item are in flight
+// beside each other instead of one launch after the other, and three launches disappear (at the
+// training shape, 2,048 ids, the launches WERE the cost).
+struct TokSet {
+    const void* tokens;
+    const int64_t* offsets;
+    const int32_t* sizes;
+    int64_t n_items;
+    int32_t* out_tokens;
+    int32_t* out_lens;
+    int elem_bytes;
+    int max_len;
+    int32_t pad;
+    int lpi;   // 0: element-wise body (unaligned output), else lanes per item of the vector body
+};
+struct TokSets {
+    TokSet s[ARTTOK_MAX_SETS];
+};
+__global__ __launch_bounds__(256) void gather_tokens_multi_kernel(TokSets sets, const int32_t* __restrict__ ids,
+                                                                  int64_t n, int32_t id_base) {
+    const TokSet& S = sets.s[blockIdx.y];
+#define BODY(E)                                                                                              \
+    do {                                                                                                     \
+        if (S.lpi)                                                                                           \
+            gather_tokens_vec_body<E>((const E*)S.tokens, S.offsets, S.sizes, S.n_items, ids, n, id_base,    \
+                                      S.max_len, S.pad, S.out_tokens, S.out_lens, S.lpi);                    \
+        else                                                                                                 \
+            gather_tokens_body<E>((const E*)S.tokens, S.offsets, S.sizes, S.n_items, ids, n, id_base,        \
+                                  S.max_len, S.pad, S.out_tokens, S.out_lens);                               \
+    } while (0)
+    switch (S.elem_bytes) {   // uniform per workgroup
+        case 1: BODY(uint8_t); break;
+        case 2: BODY(uint16_t); break;
+        case 4: BODY(int32_t); break;
+        default: BODY(int64_t); break;
+    }
+#undef BODY
 }
 
 extern "C" const char* arttok_last_error(void) { return g_tok_err; }
@@ -229,6 +291,59 @@ extern "C" int arttok_gather(arttok_t* h, const int32_t* ids_dev, int64_t n, int
         default: LAUNCH(int64_t); break;
     }
 #undef LAUNCH
+    TOK_HIP(hipGetLastError());
+    return 0;
+}
+
+// launch geometry of one dataset's gather: lanes per item of the vector body (0 = element-wise body)
+// and the workgroups it wants
+static void gather_shape(int max_len, const int32_t* out_tokens, int64_t n, int* lpi_out, int64_t* want_out) {
+    const int waves_per_block = 4;
+    const bool vec = (max_len % 4 == 0) && (((uintptr_t)out_tokens) & 15) == 0;
+    int lpi = 1;
+    while (lpi < 64 && lpi * 4 < max_len) lpi <<= 1;
+    const int64_t per_wave = vec ? 4 * (64 / lpi) : 1;   // items a wave takes per step
+    *lpi_out = vec ? lpi : 0;
+    *want_out = (n + waves_per_block * per_wave - 1) / (waves_per_block * per_wave);
+}
+
+extern "C" int arttok_gather_multi(arttok_t* const* handles, int n_sets, const int32_t* ids_dev, int64_t n,
+                                   int32_t id_base, const int32_t* max_lens, const int32_t* pads,
+                                   int32_t* const* out_tokens, int32_t* const* out_lens, void* stream) {
+    if (!handles || !ids_dev || !max_lens || !pads || !out_tokens || !out_lens)
+        return tok_fail(ARTTOK_ERR_ARG, "NULL argument");
+    if (n_sets < 1 || n_sets > ARTTOK_MAX_SETS)
+        return tok_fail(ARTTOK_ERR_ARG, "n_sets must be in [1, %d]", ARTTOK_MAX_SETS);
+    if (n < 1) return tok_fail(ARTTOK_ERR_ARG, "n must be >= 1");
+    TokSets sets;
+    memset(&sets, 0, sizeof(sets));
+    int64_t want_max = 1;
+    for (int i = 0; i < n_sets; ++i) {
+        arttok* h = handles[i];
+        if (!h || !out_tokens[i] || !out_lens[i]) return tok_fail(ARTTOK_ERR_ARG, "NULL argument (set %d)", i);
+        if (h->device != handles[0]->device)
+            return tok_fail(ARTTOK_ERR_ARG, "set %d lives on device %d, set 0 on device %d: one launch serves "
+                            "one device", i, h->device, handles[0]->device);
+        if (max_lens[i] < 1 || max_lens[i] > (1 << 20))
+            return tok_fail(ARTTOK_ERR_ARG, "max_len %d out of range (set %d)", max_lens[i], i);
+        TokSet& S = sets.s[i];
+        S.tokens = h->tokens;
+        S.offsets = h->offsets;
+        S.sizes = h->sizes;
+        S.n_items = h->n_items;
+        S.out_tokens = out_tokens[i];
+        S.out_lens = out_lens[i];
+        S.elem_bytes = h->elem_bytes;
+        S.max_len = max_lens[i];
+        S.pad = pads[i];
+        int64_t want = 1;
+        gather_shape(max_lens[i], out_tokens[i], n, &S.lpi, &want);
+        want_max = want > want_max ? want : want_max;
+    }
+    TokDeviceGuard g(handles[0]->device);
+    const unsigned grid = (unsigned)(want_max < 4096 ? want_max : 4096);
+    hipLaunchKernelGGL(gather_tokens_multi_kernel, dim3(grid, (unsigned)n_sets), dim3(256), 0, (hipStream_t)stream,
+                       sets, ids_dev, n, id_base);
     TOK_HIP(hipGetLastError());
     return 0;
 }

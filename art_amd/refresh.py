@@ -137,7 +137,8 @@ class SpmdIndexWriter(object):
     exchange can be tested on the CPU with gloo.
     """
 
-    def __init__(self, engine, n_rows, id_base=1, group=None, sink=None, device=None, flush_bytes=64 << 20):
+    def __init__(self, engine, n_rows, id_base=1, group=None, sink=None, device=None, flush_bytes=64 << 20,
+                 always_exchange=False):
         self.engine = engine
         self.n_rows = int(n_rows)
         self.id_base = int(id_base)
@@ -157,7 +158,9 @@ class SpmdIndexWriter(object):
         self.rounds = 0              # exchange rounds run so far (identical on every rank)
         self.rows_received = 0
         self.peak_buffered_bytes = 0  # accumulating batch + round in flight, the most this rank ever held
-        self._nccl = self.world > 1 and dist.get_backend(group) == "nccl"
+        # run the collectives even with one rank (measurements of the exchange path on a one-GPU box)
+        self._exchange = self.world > 1 or (always_exchange and dist.is_initialized())
+        self._nccl = self._exchange and dist.get_backend(group) == "nccl"
         if engine is not None:
             engine.begin(self.hi - self.lo)
 
@@ -208,7 +211,7 @@ class SpmdIndexWriter(object):
         self._ids, self._rows = [], []
         ids, rows, send = route_by_owner(ids, rows, self.n_rows, self.id_base, self.world)
         all_final = bool(final)
-        if self.world > 1:
+        if self._exchange:
             # "nccl" (RCCL) exchanges device buffers directly; gloo (CPU tests, or two ranks sharing
             # one GPU in the test-suite) goes through host copies and runs synchronously
             xdev = self.device if self._nccl else torch.device("cpu")
@@ -241,7 +244,7 @@ class SpmdIndexWriter(object):
         self._acc_bytes = 0
         self._note_peak()
         self.rounds += 1
-        if self.world == 1:
+        if not self._exchange:
             self._drain()
         return all_final
 

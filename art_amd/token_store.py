@@ -146,7 +146,9 @@ class MMapTokenDataset(object):
 # ---- libarttok.so ---------------------------------------------------------------------------------
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TOK_LIB_PATH = os.path.join(_HERE, "lib", "libarttok.so")
-TOK_SYMBOLS = ("arttok_create", "arttok_destroy", "arttok_gather", "arttok_info", "arttok_last_error")
+TOK_SYMBOLS = ("arttok_create", "arttok_destroy", "arttok_gather", "arttok_gather_multi", "arttok_info",
+               "arttok_last_error")
+MAX_SETS = 4  # ARTTOK_MAX_SETS
 _toklib = None
 
 
@@ -165,6 +167,8 @@ def _tok():
         lib.arttok_destroy.restype = None
         lib.arttok_gather.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp]
         lib.arttok_gather.restype = i32
+        lib.arttok_gather_multi.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp, vp, vp]
+        lib.arttok_gather_multi.restype = i32
         lib.arttok_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)]
         lib.arttok_info.restype = i32
         lib.arttok_last_error.argtypes = []
@@ -241,6 +245,41 @@ class DeviceTokenStore(object):
         return {"n_items": a.value, "n_tokens": b.value, "device_bytes": c.value}
 
 
+def gather_multi(stores, ids, max_lens=None, pads=None):
+    """`store.gather(ids)` for up to four DeviceTokenStore objects on one device in ONE launch
+    (arttok_gather_multi): the four token datasets a training step reads for the same [Q, k] winners
+    (art_model.py:367-381).  Returns a list of (tokens [..., max_len] int32, lengths [...] int32), one
+    per store.  Asynchronous on torch's current stream."""
+    stores = list(stores)
+    if not 1 <= len(stores) <= MAX_SETS:
+        raise ValueError("gather_multi takes 1 to %d stores" % MAX_SETS)
+    dev, id_base = stores[0].device, stores[0].id_base
+    if any(st.device != dev or st.id_base != id_base for st in stores):
+        raise ValueError("the stores of one gather_multi call must share a device and an id base")
+    if not ids.is_cuda or ids.dtype != torch.int32 or ids.device.index != dev:
+        raise ValueError("ids must be a CUDA int32 tensor on cuda:%d" % dev)
+    if ids.numel() < 1:
+        raise ValueError("ids is empty")
+    n_sets = len(stores)
+    if max_lens is None:
+        max_lens = [None] * n_sets
+    max_lens = [int(m) if m is not None else max(1, st.max_item_len) for m, st in zip(max_lens, stores)]
+    pads = [0] * n_sets if pads is None else [int(x) for x in pads]
+    flat = ids.contiguous().view(-1)
+    toks = [torch.empty((flat.numel(), m), dtype=torch.int32, device=ids.device) for m in max_lens]
+    lens = [torch.empty((flat.numel(),), dtype=torch.int32, device=ids.device) for _ in stores]
+    vp = ctypes.c_void_p
+    handles = (vp * n_sets)(*[st._h.value for st in stores])
+    out_t = (vp * n_sets)(*[t.data_ptr() for t in toks])
+    out_l = (vp * n_sets)(*[t.data_ptr() for t in lens])
+    ml = (ctypes.c_int32 * n_sets)(*max_lens)
+    pd = (ctypes.c_int32 * n_sets)(*pads)
+    with torch.cuda.device(ids.device):
+        _tcheck(_tok().arttok_gather_multi(handles, n_sets, vp(flat.data_ptr()), flat.numel(), id_base, ml, pd,
+                                           out_t, out_l, vp(torch.cuda.current_stream(ids.device).cuda_stream)))
+    return [(t.view(tuple(ids.shape) + (m,)), l.view(tuple(ids.shape))) for t, l, m in zip(toks, lens, max_lens)]
+
+
 def _rows_to_lists(tokens, lens):
     """[n, L] int32 + [n] lengths (host numpy) -> list of n Python lists (one bulk tolist)."""
     if (lens < 0).any():
@@ -260,7 +299,7 @@ def fetch_topk_data(topkindex, passages_bert, title_bert, passages_t0, title_t0)
     per query, ``(topkarray, [(doctext_bert, title_bert), ...], [(doctext_t0, title_t0), ...])`` where
     every leaf is a Python list of ints."""
     q, k = topkindex.shape
-    gathered = [s.gather(topkindex) for s in (passages_bert, title_bert, passages_t0, title_t0)]
+    gathered = gather_multi((passages_bert, title_bert, passages_t0, title_t0), topkindex)
     ids_host = topkindex.cpu().numpy()
     lists = [_rows_to_lists(t.view(q * k, -1).cpu().numpy(), l.view(-1).cpu().numpy()) for t, l in gathered]
     pb, tb, p0, t0 = lists
@@ -290,5 +329,5 @@ def fetch_topk_data_host(topkindex, passages_bert, title_bert, passages_t0, titl
              [(p0[r * k + j], t0[r * k + j]) for j in range(k)]) for r in range(q)]
 
 
-__all__ = ["MMapTokenDataset", "write_mmap_dataset", "DeviceTokenStore", "fetch_topk_data",
+__all__ = ["MMapTokenDataset", "write_mmap_dataset", "DeviceTokenStore", "gather_multi", "fetch_topk_data",
            "fetch_topk_data_host", "ArttokError"]

@@ -49,6 +49,15 @@ void arttok_destroy(arttok_t* h);
 int arttok_gather(arttok_t* h, const int32_t* ids_dev, int64_t n, int32_t id_base, int max_len,
                   int32_t pad, int32_t* out_tokens, int32_t* out_lens, void* stream);
 
+/* The same fetch for up to ARTTOK_MAX_SETS datasets on one device in ONE launch: the four token
+ * datasets of a training step (passages / titles, BERT / T0 vocabularies) are looked up for the same
+ * ids (art_model.py:367-381: the reference's loop reads all four per winner).  handles, max_lens,
+ * pads, out_tokens and out_lens are HOST arrays of n_sets entries; outputs as for arttok_gather. */
+#define ARTTOK_MAX_SETS 4
+int arttok_gather_multi(arttok_t* const* handles, int n_sets, const int32_t* ids_dev, int64_t n,
+                        int32_t id_base, const int32_t* max_lens, const int32_t* pads,
+                        int32_t* const* out_tokens, int32_t* const* out_lens, void* stream);
+
 /* items, tokens and bytes held on the device */
 int arttok_info(arttok_t* h, int64_t* n_items, int64_t* n_tokens, int64_t* device_bytes);
 

@@ -146,6 +146,84 @@ def test_spmd_writer_two_ranks_one_gpu(tmp_path):
     assert not os.path.exists(str(tmp_path / "spmd.flat.tmp"))
 
 
+def _stream_worker(rank, world, port, out_dir, plant_duplicate):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from art_amd.distributed import engine_spmd_search
+        from art_amd.engine import MipsEngine
+        from art_amd.refresh import SpmdIndexWriter
+        torch.cuda.set_device(0)
+        rows, queries = _data(n=12001)
+        n = rows.shape[0]
+        eng = MipsEngine(768, torch.float16, [0])
+        batch = 128
+        row_bytes = 768 * 4 + 8
+        flush = 3 * batch * row_bytes    # a round every 3 batches of this rank
+        w = SpmdIndexWriter(eng, n, id_base=1, flush_bytes=flush)
+        # the reference's sampler: global batches of consecutive ids, split contiguously over the ranks
+        n_batches = 0
+        for g0 in range(0, n, batch * world):
+            sel = np.arange(g0 + rank * batch, min(g0 + (rank + 1) * batch, n))
+            if len(sel) == 0:
+                continue
+            n_batches += 1
+            if plant_duplicate and rank == 1 and n_batches == 20:
+                sel = sel.copy()
+                sel[3] = 17           # passage 18 again, from another rank, in a LATER round than its first copy
+            w.add_block_data(torch.from_numpy(sel + 1).cuda(), torch.from_numpy(rows[sel]).cuda())
+        assert w.rounds >= 3, "the batches of this test are meant to trigger several rounds before commit"
+        outcome = "ok"
+        try:
+            w.commit()
+        except ValueError as e:
+            outcome = "dup:" + str(e)
+        except Exception as e:  # noqa: BLE001 (the missing-row error of the rank that lost a row to the duplicate)
+            outcome = "err:" + str(e)
+        # bounded buffer: own batch + one round in flight (own send + what both ranks sent here)
+        one = flush + batch * row_bytes
+        assert w.peak_buffered_bytes <= one * (2 + world), (w.peak_buffered_bytes, one)
+        assert w.peak_buffered_bytes < (n // world) * row_bytes // 2
+        with open(os.path.join(out_dir, "out%d.txt" % rank), "w") as f:
+            f.write("%s\n%d" % (outcome, w.rounds))
+        if not plant_duplicate:
+            s, i = engine_spmd_search(eng, torch.from_numpy(queries).cuda(), 30, score_dtype=torch.float32)
+            torch.cuda.synchronize()
+            np.save(os.path.join(out_dir, "s%d.npy" % rank), s.cpu().numpy())
+            np.save(os.path.join(out_dir, "i%d.npy" % rank), i.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spmd_writer_streams_in_rounds_two_ranks_one_gpu(tmp_path):
+    """Streaming refresh (indexer.py:146-165 without the filesystem): >= 3 exchange rounds before commit,
+    a bounded buffer, and the index that comes out answers like the oracle."""
+    port = 29600 + (os.getpid() % 90)
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), False), nprocs=2, join=True)
+    rows, queries = _data(n=12001)
+    ids = np.arange(1, 12002, dtype=np.int64)
+    outs = [open(tmp_path / ("out%d.txt" % r)).read().split("\n") for r in range(2)]
+    assert outs[0][0] == "ok" and outs[1][0] == "ok", outs
+    assert outs[0][1] == outs[1][1] and int(outs[0][1]) >= 10, outs   # same number of rounds on both ranks
+    for r in range(2):
+        s, i = np.load(tmp_path / ("s%d.npy" % r)), np.load(tmp_path / ("i%d.npy" % r))
+        orc.check_topk(s, i, queries.astype(np.float64), rows.astype(np.float16).astype(np.float64), ids, 30,
+                       rel_tol=1e-3)
+
+
+def test_spmd_writer_streaming_detects_a_duplicate_in_a_later_round(tmp_path):
+    """Passage 18 arrives in round 1 from rank 0 and again, many rounds later, from rank 1 in place of
+    another passage: the owner of passage 18 must fail its commit with the reference's duplicate error
+    (art_index.py:59), whatever round the copies came in."""
+    port = 29500 + (os.getpid() % 90)
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    outs = [open(tmp_path / ("out%d.txt" % r)).read().split("\n") for r in range(2)]
+    assert outs[0][0].startswith("dup:") and "overwrite block data" in outs[0][0], outs   # rank 0 owns id 18
+    assert outs[0][1] == outs[1][1], outs
+
+
 @pytest.mark.parametrize("storage", [torch.float16, torch.bfloat16])
 def test_export_after_device_refresh_roundtrip(tmp_path, storage):
     """The way back to disk after a device-side refresh (the reference's index checkpoint is the pickle

@@ -87,3 +87,28 @@ def test_large_synthetic_dataset(tmp_path):
     np.testing.assert_array_equal(tok[mask], want_flat.astype(np.int32))
     assert (tok[~mask] == 0).all()
     store.close()
+
+
+def test_gather_multi_equals_the_single_gathers():
+    """arttok_gather_multi (one launch, four datasets) against arttok_gather per dataset: identical padded
+    rows and lengths, with aligned and unaligned row widths, a pad value, and ids outside the datasets."""
+    stores = [ts.DeviceTokenStore(ts.MMapTokenDataset(os.path.join(FX, n)), device=0) for n in NAMES]
+    exp = np.load(os.path.join(FX, "expected.npz"))
+    ids = exp["topkindex"].copy()
+    ids[0, 1] = 100000      # outside every dataset: length -1, a row of pad
+    ids[1, 0] = 0
+    ids_dev = torch.from_numpy(ids).cuda()
+    for max_lens, pads in (([None] * 4, None), ([64, 8, 61, 7], [0, -1, 3, 9]), ([4, 4, 4, 4], [5, 5, 5, 5])):
+        multi = ts.gather_multi(stores, ids_dev, max_lens=max_lens, pads=pads)
+        for j, store in enumerate(stores):
+            want_t, want_l = store.gather(ids_dev, max_len=max_lens[j], pad=pads[j] if pads else 0)
+            got_t, got_l = multi[j]
+            assert torch.equal(got_t, want_t) and torch.equal(got_l, want_l), (NAMES[j], max_lens[j])
+    assert int(multi[0][1][0, 1].item()) == -1 and int(multi[0][1][1, 0].item()) == -1
+    # fewer than four stores, and the argument checks
+    two = ts.gather_multi(stores[:2], ids_dev)
+    assert torch.equal(two[1][0], stores[1].gather(ids_dev)[0])
+    with pytest.raises(ValueError):
+        ts.gather_multi(stores + stores[:1], ids_dev)
+    for s in stores:
+        s.close()

@@ -74,6 +74,28 @@ def gather_only():
 
 t_gather, _ = timed(gather_only, 50)
 
+
+def gather_fused():
+    outs = ts.gather_multi(stores, ids_dev)
+    torch.cuda.synchronize()
+    return outs
+
+t_fused, _ = timed(gather_fused, 50)
+
+
+def events_ms(fn, reps=20):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+t_gather_ev = events_ms(lambda: [s.gather(ids_dev) for s in stores])
+t_fused_ev = events_ms(lambda: ts.gather_multi(stores, ids_dev))
+
 # evaluation-set shape (3,610 queries x top-100 ids): the gather as HBM-bound byte work, timed by events
 big = torch.from_numpy(rng.integers(1, n_items + 1, size=(3610, 100)).astype(np.int32)).cuda()
 big_lines = {}
@@ -90,10 +112,20 @@ for name, store in zip(names, stores):
     elem = 2 if specs[name][0] == np.uint16 else 4
     moved = float(lens.clamp(min=0).sum().item()) * elem + big.numel() * (max_len * 4 + 4 + 4 + 12)
     big_lines[name] = {"ms": ms, "GB_moved": moved / 1e9, "GB_per_s": moved / ms / 1e6, "frac_of_8TBs": moved / ms / 1e6 / 8000.0}
+# the four datasets of the evaluation shape in one launch against four launches (device time, events)
+big_lens = [(st.max_item_len + 3) // 4 * 4 for st in stores]
+four_ms = events_ms(lambda: [st.gather(big, max_len=m) for st, m in zip(stores, big_lens)], 10)
+fused_ms = events_ms(lambda: ts.gather_multi(stores, big, max_lens=big_lens), 10)
+moved_all = sum(v["GB_moved"] for v in big_lines.values())
 norm = lambda x: json.loads(json.dumps(x))
 assert norm(got_h) == norm(want) and norm(got_d) == norm(want)
 print(json.dumps({"items_per_dataset": n_items, "ids": "64 x 32", "reference_loop_ms": t_ref * 1e3,
                   "host_batched_ms": t_host * 1e3, "device_store_to_lists_ms": t_dev * 1e3,
                   "device_gather_padded_tensors_ms": t_gather * 1e3,
+                  "device_gather_fused_one_launch_ms": t_fused * 1e3,
+                  "device_time_four_launches_ms": t_gather_ev, "device_time_fused_ms": t_fused_ev,
+                  "eval_shape_four_datasets": {"four_launches_ms": four_ms, "fused_ms": fused_ms, "GB_moved": moved_all,
+                                               "fused_GB_per_s": moved_all / fused_ms * 1e3,
+                                               "fused_frac_of_8TBs": moved_all / fused_ms * 1e3 / 8000.0},
                   "device_bytes": sum(s.info()["device_bytes"] for s in stores),
                   "eval_shape_gather_3610x100": big_lines}))

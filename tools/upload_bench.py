@@ -69,6 +69,33 @@ for dt, name in ((torch.float16, "scatter fp16 batches"), (torch.float32, "scatt
                           "frac_of_8TBs": moved / ms / 1e6 / 8000.0, "rows_per_s": big / ms * 1e3}), flush=True)
     del d_rows
 
+# the streaming SPMD writer (art_amd/refresh.py): the indexer's 1,024-row batches through add_block_data,
+# exchange rounds every 64 MiB over RCCL (one rank here: the all_to_alls run, the peer is this rank itself)
+import torch.distributed as dist  # noqa: E402
+from art_amd.refresh import SpmdIndexWriter  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+d_rows = torch.from_numpy(rows).cuda()
+d_ids = torch.arange(1, n + 1, device="cuda", dtype=torch.int64)
+for always in (False, True):
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w = SpmdIndexWriter(eng, n, id_base=1, always_exchange=always)
+        for b in range(0, n, 1024):
+            w.add_block_data(d_ids[b:b + 1024], d_rows[b:b + 1024])
+        w.commit()
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+    print(json.dumps({"path": "SpmdIndexWriter stream, 1,024-row fp16 batches, " +
+                              ("RCCL all_to_all rounds (world 1)" if always else "no exchange (world 1)"),
+                      "rows": n, "rounds": w.rounds, "seconds": t, "rows_per_s": n / t,
+                      "peak_buffered_MB": w.peak_buffered_bytes / 1e6}), flush=True)
+del d_rows
+dist.destroy_process_group()
+
 m = min(n, 200000)
 store = OpenRetreivalDataStore("/tmp/_bench_store.pkl", load_from_path=False, rank=0)
 t0 = time.perf_counter()
