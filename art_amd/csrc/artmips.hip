@@ -1091,8 +1091,32 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         a.n_work = p.n_tiles;
         a.tile_stride = 1;
     }
+#ifdef ARTMIPS_STAMPS_BUILD
+    // ARTMIPS_STAMPS=1: clock stamps of one iteration of one workgroup of this launch, printed per wave as
+    // cycles since the iteration's first stamp (tools/r3/stamps.sh); the search waits for the launch
+    static unsigned long long* stamp_buf = nullptr;
+    const bool stamps = diag_int("ARTMIPS_STAMPS", 0) != 0;
+    if (stamps) {
+        if (!stamp_buf) HIP_TRY(hipMalloc((void**)&stamp_buf, 8 * 24 * 8));
+        HIP_TRY(hipMemsetAsync(stamp_buf, 0, 8 * 24 * 8, st));
+        a.stamps = stamp_buf;
+    }
+#endif
     rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid * p.gang, st);
     if (rc) return rc;
+#ifdef ARTMIPS_STAMPS_BUILD
+    if (stamps) {
+        unsigned long long hst[8 * 24];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(hst, stamp_buf, sizeof(hst), hipMemcpyDeviceToHost));
+        for (int w = 0; w < p.nw; ++w) {
+            fprintf(stderr, "[stamps nw=%d nq=%d gang=%d wave %d]", p.nw, p.nq, p.gang, w);
+            for (int i = 0; i < 24; ++i)
+                if (hst[w * 24 + i]) fprintf(stderr, " %d:%lld", i, (long long)(hst[w * 24 + i] - hst[w * 24]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (timed) HIP_TRY(hipEventRecord(s.ev_scan[2 * tile_index + 1], st));
     DEBUG_STEP(st, "scan<FILTER> grid=%d nq=%d nw=%d stg=%d cap=%d tiles=%lld rows=%lld q_count=%d q_rows=%d",
                p.grid, p.nq, p.nw, (int)p.stage_lds, p.cap, p.n_tiles, (long long)gen.n_rows, q_count, q_rows);

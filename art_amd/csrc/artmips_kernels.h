@@ -186,6 +186,8 @@ struct ScanArgs {
     // only, STG == 0).
     int tile_skip;
     int counts_continue;
+    unsigned long long* stamps;  // diagnostic build only (ARTMIPS_STAMPS): [8 waves][24] shader-clock stamps of one
+                                 // iteration of one workgroup (see ARTMIPS_STAMP in scan_kernel); NULL = off
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE).  Bits 1..32 switch
                           // parts of the loop off (results are then meaningless): 1 = no refill DMA, 2 = no
                           // barrier, 4 = no compute, 8 = no LDS reads, 16 = no filter, 32 = reads never waited
@@ -274,15 +276,69 @@ __device__ __forceinline__ void glds16_pieces(const void* base, const uint32_t* 
 // pieces per M0 value for a wave that issues PPW pieces of a stage
 constexpr int dma_group_size(int ppw) { return ppw <= 4 ? ppw : (ppw % 6 == 0 ? 6 : (ppw % 4 == 0 ? 4 : (ppw % 3 == 0 ? 3 : 1))); }
 
-// Largest of four scores in two instructions.  fmaxf() costs five here: hipcc canonicalises two of the
-// inputs first (v_max x, x) because they come out of inline asm.  NaNs are ignored like fmaxf ignores
-// them (MFMA results are never signalling), which is all the filter's pre-check needs: some element
-// >= thr implies max4 >= thr.
-__device__ __forceinline__ float max4(const f32x4& v) {
-    float m;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
-    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v[3]));
-    return m;
+// Pre-check of the filter for NQ column groups in ONE asm statement: does any lane of the wave hold a score
+// >= its threshold in any group?  Two instructions find a lane's largest score of a group (NaNs are ignored
+// as fmaxf ignores them; MFMA results are never signalling), one compares it, the lane masks are ORed
+// on the scalar unit.  Written as one statement because every instruction outside the MFMAs costs a
+// lone wave 6-8 cycles: left to hipcc the same test took ~45 instructions (pads after each asm VALU
+// result, a ballot rebuilt through v_cndmask / v_cmp) and 325 cycles a stage (profiles/r03_c_stamps.txt).
+template <int NQ>
+__device__ __forceinline__ bool any_survivor(const f32x4* acc, const float* thr) {
+    static_assert(NQ >= 2 && NQ <= 4, "multi-group shapes");
+    unsigned long long m0, m1, m2 = 0, m3 = 0;
+    float t0, t1;
+    if constexpr (NQ == 2) {
+        asm volatile("v_max3_f32 %2, %4, %5, %6\n\t"
+                     "v_max3_f32 %3, %8, %9, %10\n\t"
+                     "v_max_f32 %2, %2, %7\n\t"
+                     "v_max_f32 %3, %3, %11\n\t"
+                     "v_cmp_ge_f32 %0, %2, %12\n\t"
+                     "v_cmp_ge_f32 %1, %3, %13\n\t"
+                     "s_or_b64 %0, %0, %1"
+                     : "=&s"(m0), "=&s"(m1), "=&v"(t0), "=&v"(t1)
+                     : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                       "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]), "v"(thr[0]), "v"(thr[1]));
+    } else if constexpr (NQ == 3) {
+        asm volatile("v_max3_f32 %3, %5, %6, %7\n\t"
+                     "v_max3_f32 %4, %9, %10, %11\n\t"
+                     "v_max_f32 %3, %3, %8\n\t"
+                     "v_max_f32 %4, %4, %12\n\t"
+                     "v_cmp_ge_f32 %0, %3, %17\n\t"
+                     "v_cmp_ge_f32 %1, %4, %18\n\t"
+                     "v_max3_f32 %3, %13, %14, %15\n\t"
+                     "v_max_f32 %3, %3, %16\n\t"
+                     "v_cmp_ge_f32 %2, %3, %19\n\t"
+                     "s_or_b64 %0, %0, %1\n\t"
+                     "s_or_b64 %0, %0, %2"
+                     : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&v"(t0), "=&v"(t1)
+                     : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                       "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]),
+                       "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[2][2]), "v"(acc[2][3]),
+                       "v"(thr[0]), "v"(thr[1]), "v"(thr[2]));
+    } else {
+        asm volatile("v_max3_f32 %4, %6, %7, %8\n\t"
+                     "v_max3_f32 %5, %10, %11, %12\n\t"
+                     "v_max_f32 %4, %4, %9\n\t"
+                     "v_max_f32 %5, %5, %13\n\t"
+                     "v_cmp_ge_f32 %0, %4, %22\n\t"
+                     "v_cmp_ge_f32 %1, %5, %23\n\t"
+                     "v_max3_f32 %4, %14, %15, %16\n\t"
+                     "v_max3_f32 %5, %18, %19, %20\n\t"
+                     "v_max_f32 %4, %4, %17\n\t"
+                     "v_max_f32 %5, %5, %21\n\t"
+                     "v_cmp_ge_f32 %2, %4, %24\n\t"
+                     "v_cmp_ge_f32 %3, %5, %25\n\t"
+                     "s_or_b64 %0, %0, %1\n\t"
+                     "s_or_b64 %2, %2, %3\n\t"
+                     "s_or_b64 %0, %0, %2"
+                     : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&v"(t0), "=&v"(t1)
+                     : "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]),
+                       "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]),
+                       "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[2][2]), "v"(acc[2][3]),
+                       "v"(acc[3][0]), "v"(acc[3][1]), "v"(acc[3][2]), "v"(acc[3][3]),
+                       "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]));
+    }
+    return m0 != 0ull;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -334,6 +390,10 @@ __device__ __forceinline__ void mg_mfma_groups(f32x4* acc, const V& a, const V (
         mg_mfma_groups<T, NQ, KSTEPS, VB, S, J + 1, V>(acc, a, bq);
     }
 }
+// (Tried in round 3 and dropped: the fragment of k-step I of chunk C + 2 requested right behind the MFMAs
+// of k-step I of chunk C, i.e. the LDS reads riding in the issue gaps between MFMAs instead of four
+// together in front of a chunk.  The stamped iteration got no shorter and the launch 3-5 % slower:
+// profiles/r03_a_gang_ab.txt, build v2.)
 template <typename T, int NQ, int KSTEPS, int VB, int C, int CH, int I, typename V>
 __device__ __forceinline__ void mg_mfma_chunk(f32x4* acc, const V* af, const V (*bq)[KSTEPS]) {
     if constexpr (I < CH) {
@@ -353,7 +413,20 @@ struct MgDma {
     bool late;               // uniform: this wave issues in the second half of the phase
     bool noread;             // diagnostic build only (ARTMIPS_ABLATE & 8): skip the LDS reads and waits
     bool nowait;             // diagnostic build only (ARTMIPS_ABLATE & 32): issue the LDS reads, never wait
+    bool stamp;              // diagnostic build only: this iteration records clock stamps into st[]
+    unsigned long long* st;
 };
+// In-kernel stamps (a build of their own: -DARTMIPS_DIAG -DARTMIPS_STAMPS_BUILD -> libartmips_stamps.so, run
+// with ARTMIPS_STAMPS=1): s_memtime into a scalar pair, no wait (the counter it shares with the LDS reads is
+// drained once, at the end of the stamped iteration), one iteration of one workgroup only.  The stamped
+// iteration itself is slightly disturbed (a counted lgkmcnt wait may be satisfied by a stamp instead of a
+// row fragment: its scores are then garbage) and the uniform branch around every stamp costs all other
+// iterations a few per cent: the build is for reading where an iteration's cycles go, nothing else.
+#ifdef ARTMIPS_STAMPS_BUILD
+#define ARTMIPS_STAMP(on, arr, i) do { if (on) asm volatile("s_memtime %0" : "=s"((arr)[i])); } while (0)
+#else
+#define ARTMIPS_STAMP(on, arr, i) do { } while (0)
+#endif
 template <int AUX, int PPW, int NCH, int NW, int C, int PP>
 __device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
     if constexpr (PP < PPW) {
@@ -382,12 +455,17 @@ __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq
             if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
             if constexpr (C + 1 < NCH) mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
         }
-        if constexpr (C == 0) pre();
+        if constexpr (C == 0) {
+            ARTMIPS_STAMP(d.stamp, d.st, 4);
+            pre();
+            ARTMIPS_STAMP(d.stamp, d.st, 5);
+        }
         if (!d.noread && !d.nowait) {
             if constexpr (C + 1 < NCH) mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
             else mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
         }
         mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
+        ARTMIPS_STAMP(d.stamp, d.st, 6 + C);
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, 0>(d);
         mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, C + 1, V, Pre>(acc, af, bq, base, d, pre);
     }
@@ -570,29 +648,33 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t t_q0 = div_mod((uint32_t)b, &t_r0);
     struct TileWalk {
         uint32_t q, r;
-        uint32_t left;    // work items of this workgroup from the current one on (>= 1 while it has any)
     };
-    auto walk_begin = [&]() __attribute__((always_inline)) -> TileWalk {
-        // (n_it comes out of a 64-bit division that hipcc expands on the vector unit)
-        return TileWalk{t_q0, t_r0, (uint32_t)__builtin_amdgcn_readfirstlane((int)n_it)};
-    };
-    // the current tile, then one step on; past the workgroup's last item the walk stays on it (the
-    // ring's tail refills re-read that tile: any valid address keeps the vmcnt arithmetic uniform)
+    const uint32_t t_last = (uint32_t)((n_rows + TILE_ROWS - 1) / TILE_ROWS - 1);   // last tile of the shard
+    // the current tile, then one step on.  Past the workgroup's last item (the ring's tail refills) the
+    // walk runs on and is clamped to the shard's last tile: any valid address keeps the vmcnt
+    // arithmetic uniform, the data is never used.
     auto walk_next = [&](TileWalk& t) __attribute__((always_inline)) -> long long {
+        uint32_t tile = t.q * t_mult + t.r + t_add;
+        tile = tile < t_last ? tile : t_last;
         // (readfirstlane: the DMA takes its base from scalar registers, and hipcc must not move this
         // chain of uniform values to the vector unit)
-        const long long tile = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(t.q * t_mult + t.r + t_add));
-        const bool more = t.left > 1;
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         uint32_t nr = t.r + t_dr;
         const uint32_t carry = nr >= t_mod ? 1u : 0u;
-        nr -= carry ? t_mod : 0u;
-        t.r = more ? nr : t.r;
-        t.q = more ? t.q + t_dq + carry : t.q;
-        t.left -= more ? 1u : 0u;
-        return tile;
+        t.r = nr - (carry ? t_mod : 0u);
+        t.q += t_dq + carry;
+        return (long long)tile;
     };
-    TileWalk walk_issue = walk_begin();   // stages are issued in order: prologue, then one per iteration
-    TileWalk walk_filter = walk_begin();  // and filtered in order, once each
+    TileWalk walk_issue{t_q0, t_r0};      // stages are issued in order: prologue, then one per iteration
+    // the filter asks for a stage's tile only when the stage has survivors: direct formula there
+    auto tile_of = [&](long long wk) __attribute__((always_inline)) -> long long {
+        if (a.tile_skip) {
+            const uint32_t w32 = (uint32_t)wk;
+            return (a.tile_skip == 8) ? (long long)((w32 / 7u) * 8u + w32 % 7u + 1u)
+                                      : (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
+        }
+        return wk * stride;
+    };
 
     // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
     // (DMA side): slot pos = p*64+lane of the stage holds chunk (pos % CPR) ^ (row & 15) of row pos / CPR
@@ -658,17 +740,15 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // Filter (or pass-0 maxima) of one finished stage: acc[j][i] = score(row = tile*16 + g*4 + i,
     // query = j*QG + w*16 + r)
     f32x4 acc[NQ];   // multi-group path: lives across iterations (its filter runs one stage late)
-    auto epilogue = [&](f32x4* acc) __attribute__((always_inline)) {
-        const long long row_base = walk_next(walk_filter) * TILE_ROWS + g * 4;
+    auto epilogue = [&](long long it_e, f32x4* acc) __attribute__((always_inline)) {
         if constexpr (MODE == MODE_FILTER && NQ > 1) {
             // the common case (no survivor in any column group of this wave) leaves through ONE branch
             if (!(ablate & (16 | 256))) {
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) any |= max4(acc[j]) >= thr[j];
-                if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+                if (!any_survivor<NQ>(acc, thr)) return;
             }
         }
+        // (only a stage with survivors, and pass 0, need to know which rows these are)
+        const long long row_base = tile_of(b + it_e * grid) * TILE_ROWS + g * 4;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (ablate & 16) {
@@ -724,10 +804,23 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
 
         int slot = 0;
+#ifdef ARTMIPS_STAMPS_BUILD
+        unsigned long long st[24];
+        const bool stamp_wg = a.stamps != nullptr && blockIdx.x == 137u % gridDim.x;
+#endif
         for (long long it = 0; it < n_it; ++it) {
+#ifdef ARTMIPS_STAMPS_BUILD
+            const bool stamp_now = stamp_wg && it == n_it / 2;
+#else
+            constexpr bool stamp_now = false;
+            unsigned long long* const st = nullptr;
+#endif
+            ARTMIPS_STAMP(stamp_now, st, 0);
             // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
             wait_vmcnt<(NSTAGE - 2) * PPW>();
+            ARTMIPS_STAMP(stamp_now, st, 1);
             if (!(ablate & 2)) asm volatile("s_barrier" ::: "memory");
+            ARTMIPS_STAMP(stamp_now, st, 2);
             // every wave has finished reading the slot consumed in the previous iteration: refill it.
             // On the multi-group path a working wave spreads the refill over its compute phase
             // (mg_compute) when the tile is whole; otherwise all pieces go out here.
@@ -735,6 +828,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             dma.on = false;
             dma.noread = (ablate & 8) != 0;
             dma.nowait = (ablate & 32) != 0;
+            dma.stamp = stamp_now;
+            dma.st = st;
             if constexpr (ASM_PATH && INLINE_DMA) {
                 dma.on = wave_active && !(ablate & 1);
                 // (an idle wave, or the diagnostic build without the refill, issues through issue_stage or
@@ -750,6 +845,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             // fragments of a stage requested before its wait and barrier, with one stage less of
             // look-ahead: +-0.5 % in the gang shapes)
             if (!dma.on && !(ablate & 1)) issue_stage();
+            ARTMIPS_STAMP(stamp_now, st, 3);
             fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
 
             if (wave_active) {
@@ -780,7 +876,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                         __builtin_amdgcn_sched_group_barrier(0x100, CHB, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, CHB * NQ * MPF, 0);
                     }
-                    epilogue(acc);
+                    epilogue(it, acc);
                 } else {
                     // chunks of CH k-steps, row fragments double-buffered in registers; the filter of
                     // the PREVIOUS stage runs inside, behind the first LDS read requests (mg_compute)
@@ -791,18 +887,29 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                     auto pre = [&]() __attribute__((always_inline)) {
                         if (it > 0) {
                             mg_settle_short<NQ, 0>(acc);
-                            epilogue(acc);
+                            epilogue(it - 1, acc);
                         }
                     };
                     mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma, pre);
                 }
             }
+            ARTMIPS_STAMP(stamp_now, st, 20);
+#ifdef ARTMIPS_STAMPS_BUILD
+            if (stamp_now) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 24; ++i)
+                        a.stamps[w * 24 + i] = (i <= 5 || i == 20 || (i >= 6 && i < 6 + NCH)) ? st[i] : 0ull;
+                }
+            }
+#endif
             slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
         }
         if constexpr (NQ > 1) {
             if (wave_active) {   // the last stage's filter (every other stage's ran inside the next one)
                 mg_settle<NQ, 0>(acc);
-                epilogue(acc);
+                epilogue(n_it - 1, acc);
             }
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
