@@ -313,6 +313,15 @@ static int launch_scan_dt(int dim, int nq, int nw, int mode, const ScanArgs& a, 
         if (nq == 1) return launch_scan_t<T, 1024, 4, 2, 1, STG>(mode, a, grid, st);
         if (nq == 2) return launch_scan_t<T, 1024, 4, 2, 2, STG>(mode, a, grid, st);
     }
+    // the other multiples of 128 below 1,024: one column group per sweep (a search with more than 64
+    // queries streams the shard once per 64 of them); ring depth = what 144 KiB of LDS hold
+    if (nq == 1) {
+        if (dim == 256) return launch_scan_t<T, 256, 8, 2, 1, STG>(mode, a, grid, st);
+        if (dim == 384) return launch_scan_t<T, 384, 8, 2, 1, STG>(mode, a, grid, st);
+        if (dim == 512) return launch_scan_t<T, 512, 8, 2, 1, STG>(mode, a, grid, st);
+        if (dim == 640) return launch_scan_t<T, 640, 7, 2, 1, STG>(mode, a, grid, st);
+        if (dim == 896) return launch_scan_t<T, 896, 5, 2, 1, STG>(mode, a, grid, st);
+    }
     if (dim == 128) {
         if (nq == 1) return launch_scan_t<T, 128, 8, 2, 1, STG>(mode, a, grid, st);
         if (nq == 2) return launch_scan_t<T, 128, 8, 2, 2, STG>(mode, a, grid, st);
@@ -339,11 +348,15 @@ static int launch_scan(int dtype, int dim, int nq, int nw, bool stage_lds, int m
 }
 
 // column groups per pass the kernels are built for at this width
-static int max_nq(int dim, int dtype) { return dtype == ARTMIPS_F32 ? 1 : (dim == 1024 ? 2 : MAX_NQ); }
+static int max_nq(int dim, int dtype) {
+    if (dtype == ARTMIPS_F32) return 1;
+    if (dim == 768 || dim == 128) return MAX_NQ;
+    return dim == 1024 ? 2 : 1;
+}
 
 static bool dim_supported(int dim, int dtype) {
     if (dtype == ARTMIPS_F32) return dim == 768 || dim == 128;
-    return dim == 768 || dim == 1024 || dim == 128;
+    return dim >= 128 && dim <= 1024 && dim % 128 == 0;   // f16 / bf16: every multiple of 128 up to 1,024
 }
 
 static std::atomic<bool> g_kth_attr[ARTMIPS_MAX_DEVICES * 4] = {};
@@ -420,7 +433,7 @@ extern "C" int artmips_create(const int* device_ids, int n_dev, int dim, int sto
                     storage_dtype);
     if (!dim_supported(dim, storage_dtype))
         return fail(ARTMIPS_ERR_UNSUPPORTED,
-                    "dim %d: kernels are built for 128, 768 and 1024 (f16/bf16) or 128 and 768 (f32)", dim);
+                    "dim %d: kernels are built for the multiples of 128 up to 1024 (f16/bf16) or 128 and 768 (f32)", dim);
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     for (int i = 0; i < n_dev; ++i)

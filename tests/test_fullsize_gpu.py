@@ -126,8 +126,13 @@ def test_c3_eval_set_one_call(big):
     q = torch.cat([queries, more], 0)
     s, i = eng.search(q, 100, score_dtype=torch.float32)
     info = eng.info()
-    # gangs of 8, 4 and 2 workgroups x 256 queries (2,048 + 1,024 + 512), and the last 26 queries on their own
-    assert info["last_retries"] == 0 and info["last_scan_launches"] == 4
+    # on a 256-CU part: gangs of 8, 4 and 2 workgroups x 256 queries (2,048 + 1,024 + 512), and the last 26
+    # queries on their own; a part whose CU count allows smaller gangs only takes more launches, never more
+    # than one per 256 queries
+    assert info["last_retries"] == 0
+    if info["n_cu"] % 64 == 0:
+        assert info["last_scan_launches"] == 4
+    assert 4 <= info["last_scan_launches"] <= -(-3610 // 256)
     assert bool((s[:, :-1] >= s[:, 1:]).all()) and bool((i > 0).all()) and bool((i <= N).all())
     for j, p in enumerate(planted):
         assert int(i[j, 0]) == p + 1

@@ -177,3 +177,40 @@ def test_stray_library_variable_is_ignored_without_the_opt_in():
     env["ARTMIPS_LIBRARY"] = os.path.join(ROOT, "art_amd", "lib", "libartmips_diag.so")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("libartmips.so"), r.stdout + r.stderr
+
+
+# ---- every multiple of 128 up to 1,024 (round 3): the widths between the three the first rounds built
+@pytest.mark.parametrize("dim", [256, 384, 512, 640, 896])
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
+def test_other_widths_vs_oracle(gu, dim, storage):
+    st = torch.float16 if storage == "f16" else torch.bfloat16
+    rng = np.random.Generator(np.random.PCG64(7300 + dim))
+    for n, q, k in ((3001, 5, 17), (40000, 150, 32), (30000, 9, 300)):   # no pass 0 | pass 0 + three sweeps | large k
+        rows = (rng.standard_normal((n, dim)) * 0.05).astype(np.float32)
+        queries = rng.standard_normal((q, dim)).astype(np.float32)
+        ids = (rng.permutation(n) + 1).astype(np.int32)
+        eng = gu.build_engine(rows, ids, storage=st)
+        s, i = gu.search_np(eng, queries, k, q_dtype=torch.float32)
+        n_diff = orc.check_topk(s, i, orc.to_storage(queries, storage), orc.to_storage(rows, storage), ids, k,
+                                rel_tol=1e-3)
+        assert n_diff <= max(2, (q * k) // 500), "%d id positions differ from the oracle" % n_diff
+        assert eng.info()["last_retries"] == 0
+        eng.close()
+
+
+@pytest.mark.parametrize("dim", [256, 640, 896])
+def test_other_widths_integer_ties_bit_exact(gu, dim):
+    """Integer-valued rows with planted duplicates: every dot product is exact in fp32 in any order, ties
+    are real, and the answer must equal the oracle's bit for bit (score desc, id asc)."""
+    rng = np.random.Generator(np.random.PCG64(7400 + dim))
+    n, q, k = 20000, 6, 40
+    rows = rng.integers(-4, 5, size=(n, dim)).astype(np.float16)
+    queries = rng.integers(-4, 5, size=(q, dim)).astype(np.float16)
+    for t in range(30):
+        rows[(997 * t + 5) % n] = rows[t]          # duplicates of rows that may well be in a top-k
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    eng = gu.build_engine(rows, ids)
+    s, i = gu.search_np(eng, queries, k)
+    want_s, want_i, _ = orc.exact_topk(queries.astype(np.float64), rows.astype(np.float64), ids, k)
+    assert np.array_equal(i, want_i) and np.array_equal(s, want_s)
+    eng.close()
