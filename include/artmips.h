@@ -92,7 +92,13 @@ typedef struct artmips_info {
 /* Replaces DistributedBruteForceIndex.__init__ (art_index.py:201-209): one handle
  * owning one row shard per entry of device_ids (art_index.py:204 uses every visible
  * GPU).  The same device id may be listed more than once (two shards on one GPU);
- * n_dev == 1 is the per-rank form used by the SPMD path. */
+ * n_dev == 1 is the per-rank form used by the SPMD path.
+ * dim: any multiple of 128 up to 1024 for f16 / bf16 rows (768 = the reference's BERT-base width,
+ * 128 and 768 also score up to 256 queries per sweep and 768 runs large batches in gangs, 1024 up to
+ * 128 per sweep, the other widths 64); 128 or 768 for f32 rows.  The call also sets the function
+ * attributes of every kernel the handle can launch, so that no search ever does (a search can be
+ * enqueued under HIP graph capture).  Devices without peer access to one another are accepted: the
+ * copies between them are then staged by the runtime. */
 int artmips_create(const int* device_ids, int n_dev, int dim, int storage_dtype, artmips_t** out);
 
 /* Frees every device buffer.  Replaces `del self.evidence_embeds`

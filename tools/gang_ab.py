@@ -45,7 +45,9 @@ for name, val in arms:  # warm every arm (first-use attribute calls, buffer grow
     if ref is None:
         ref = i.clone()
     else:
-        assert torch.equal(ref, i), "arm %s returns other ids than arm %s" % (name, arms[0][0])
+        # (GANG_AB_NOCHECK=1: arms that switch parts of the loop off, bits 1..32, return garbage by design)
+        assert os.environ.get("GANG_AB_NOCHECK") or torch.equal(ref, i), \
+            "arm %s returns other ids than arm %s" % (name, arms[0][0])
 for r in range(rounds):
     order = arms if r % 2 == 0 else arms[::-1]
     for name, val in order:
