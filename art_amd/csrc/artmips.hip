@@ -1816,10 +1816,14 @@ extern "C" int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_
         if (local.empty()) continue;
         DeviceGuard g(s.dev);
         const size_t m = local.size();
-        void *d_pos = nullptr, *d_out = nullptr;
-        hipError_t e = hipMalloc(&d_pos, m * 8);
-        if (e == hipSuccess) e = hipMalloc(&d_out, m * (size_t)h->dim * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_pos, local.data(), m * 8, hipMemcpyHostToDevice, s.stream);
+        // the shard's grow-on-demand scratch (kept between calls): positions in, fp32 rows out
+        int rc = 0;
+        HIP_TRY(hipStreamSynchronize(s.stream));   // nothing of an earlier call still uses the two buffers
+        if ((rc = ensure(s.loc_ids, m * 8))) return rc;
+        if ((rc = ensure(s.loc_scores, m * (size_t)h->dim * 4))) return rc;
+        void* const d_pos = s.loc_ids.p;
+        void* const d_out = s.loc_scores.p;
+        hipError_t e = hipMemcpyAsync(d_pos, local.data(), m * 8, hipMemcpyHostToDevice, s.stream);
         if (e == hipSuccess) {
             if (h->dtype == ARTMIPS_F16) launch_gather<_Float16>(s.live, h->dim, (const long long*)d_pos, (long long)m, (float*)d_out, s.stream);
             else if (h->dtype == ARTMIPS_BF16) launch_gather<__bf16>(s.live, h->dim, (const long long*)d_pos, (long long)m, (float*)d_out, s.stream);
@@ -1829,8 +1833,6 @@ extern "C" int artmips_fetch_rows(artmips_t* h, const int64_t* positions, int64_
         tmp.resize(m * (size_t)h->dim);
         if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d_out, m * (size_t)h->dim * 4, hipMemcpyDeviceToHost, s.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-        if (d_pos) (void)hipFree(d_pos);
-        if (d_out) (void)hipFree(d_out);
         if (e != hipSuccess) return fail(ARTMIPS_ERR_HIP, "row fetch on shard %d failed: %s", sidx, hipGetErrorString(e));
         for (size_t j = 0; j < m; ++j)
             memcpy(out_host + (size_t)where[j] * h->dim, tmp.data() + j * (size_t)h->dim, (size_t)h->dim * 4);

@@ -19,9 +19,9 @@ rng = np.random.Generator(np.random.PCG64(seed))
 t_start = time.time()
 bad = 0
 for c in range(cases):
-    dim = int(rng.choice([128, 768, 768, 768, 1024]))
+    dim = int(rng.choice([128, 768, 768, 768, 1024, 256, 384, 512, 640, 896]))
     storage = str(rng.choice(["f16", "f16", "bf16", "f32"]))
-    if storage == "f32" and dim == 1024:
+    if storage == "f32" and dim not in (128, 768):
         dim = 768
     big = os.environ.get("STRESS_BIG") == "1"  # larger shards, multi-sweep query counts
     n = int(np.exp(rng.uniform(np.log(2000 if big else 1), np.log(400000 if big else 150000))))
