@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace artk {
 
@@ -51,6 +52,9 @@ enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
 #define ARTMIPS_MFMA_PAD "s_nop 1\n\t"
 #endif
 
+#ifndef ARTMIPS_PHASED
+#define ARTMIPS_PHASED 1   // 0: the 8-wave loop of rounds 1-2 (A/B builds only)
+#endif
 template <typename T> struct Elem;
 template <> struct Elem<_Float16> {
     typedef half8 V;
@@ -214,6 +218,8 @@ struct ScanArgs {
 // instead of per piece: the scalar instructions around a piece cost the issuing wave as much as the
 // piece itself when it is the only wave on its SIMD.
 constexpr int DMA_BIAS = 2048;
+// (the gang kernels' refill with the cache policy bits sc1, sc0, sc0 sc1 instead of none: +-0.5 %,
+// profiles/r03_d_phased_ab.txt)
 #define ARTMIPS_GLDS_LINE(op, off, nt) "global_load_lds_dwordx4 %" #op ", %2 offset:" #off nt "\n\t"
 #define ARTMIPS_GLDS_HEAD "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
 #define ARTMIPS_GLDS_TAIL "s_mov_b32 m0, %0"
@@ -446,28 +452,45 @@ __device__ __forceinline__ void mg_dma_after_chunk(const MgDma& d) {
 // wait for them: the place where the previous stage's filter epilogue costs least (its VALU work
 // overlaps the LDS latency, and the MFMA results it reads have settled while the wave sat at the
 // barrier).
-template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int AUX, int PPW, int NW, int C, typename V,
-          typename Pre>
+// ROLE 1 (the second wave of a SIMD in the phased 8-wave loop, see scan_kernel): chunks 0 and 1 were
+// requested by the caller in front of the stage's barrier, and `pre` does not run here.
+// The row fragments live in NBUF register buffers of CH k-steps; chunk C + NBUF - 1 is requested in front
+// of the MFMAs of chunk C (NBUF = 2: the next chunk; NBUF = 4 with CH = 1: three k-steps ahead, which
+// covers the LDS latency with the few registers the 8-wave shape has left, even while the other wave of
+// the SIMD is not computing).
+template <int NBUF, int CH, int K, typename V>
+__device__ __forceinline__ void mg_load_first(V (*af)[CH], const uint32_t (&base)[4]) {
+    if constexpr (K < NBUF - 1) {
+        mg_load_chunk<K, CH, 0, V>(af[K], base);
+        mg_load_first<NBUF, CH, K + 1, V>(af, base);
+    }
+}
+template <typename T, int NQ, int KSTEPS, int VB, int NCH, int CH, int NBUF, int AUX, int PPW, int NW, int C,
+          int ROLE, typename V, typename Pre>
 __device__ __forceinline__ void mg_compute(f32x4* acc, V (*af)[CH], const V (*bq)[KSTEPS],
                                            const uint32_t (&base)[4], const MgDma& d, const Pre& pre) {
     if constexpr (C < NCH) {
+        constexpr int PD = NBUF - 1;   // chunks of look-ahead
+        static_assert(NCH >= NBUF - 1, "more look-ahead than chunks");
         if (!d.noread) {
-            if constexpr (C == 0) mg_load_chunk<0, CH, 0, V>(af[0], base);
-            if constexpr (C + 1 < NCH) mg_load_chunk<C + 1, CH, 0, V>(af[(C + 1) & 1], base);
+            if constexpr (C == 0 && ROLE == 0) mg_load_first<NBUF, CH, 0, V>(af, base);
+            if constexpr (C + PD < NCH) mg_load_chunk<C + PD, CH, 0, V>(af[(C + PD) % NBUF], base);
         }
-        if constexpr (C == 0) {
+        if constexpr (C == 0 && ROLE == 0) {
             ARTMIPS_STAMP(d.stamp, d.st, 4);
             pre();
             ARTMIPS_STAMP(d.stamp, d.st, 5);
         }
         if (!d.noread && !d.nowait) {
-            if constexpr (C + 1 < NCH) mg_wait_chunk<CH, CH, 0, V>(af[C & 1]);   // LDS returns in order: chunk C is back
-            else mg_wait_chunk<0, CH, 0, V>(af[C & 1]);
+            // LDS returns in order: with the chunks younger than C still out, chunk C is back
+            constexpr int YOUNGER = (NCH - 1 - C < PD) ? NCH - 1 - C : PD;
+            mg_wait_chunk<YOUNGER * CH, CH, 0, V>(af[C % NBUF]);
         }
-        mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C & 1], bq);
-        ARTMIPS_STAMP(d.stamp, d.st, 6 + C);
+        mg_mfma_chunk<T, NQ, KSTEPS, VB, C, CH, 0, V>(acc, af[C % NBUF], bq);
+        constexpr int SDIV = NCH > 12 ? NCH / 12 : 1;   // at most 12 stamps inside a stage
+        if constexpr (C % SDIV == SDIV - 1) ARTMIPS_STAMP(d.stamp, d.st, 6 + C / SDIV);
         mg_dma_after_chunk<AUX, PPW, NCH, NW, C, 0>(d);
-        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, C + 1, V, Pre>(acc, af, bq, base, d, pre);
+        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, NBUF, AUX, PPW, NW, C + 1, ROLE, V, Pre>(acc, af, bq, base, d, pre);
     }
 }
 // MFMA results must not be read by ordinary VALU code before the pipeline has written them:
@@ -593,8 +616,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     }
     const bool wave_active = (w * 16) < q_count && !(ablate & 4);   // group 0 of this wave has a real query
     // row-operand fragments are read in NCH chunks when the query operand leaves too few registers
-    constexpr int NCH = (KSTEPS >= 24) ? ((NW == 8) ? ((NQ >= 2) ? 12 : 8) : (NQ >= 4) ? 6 : 4) : 1;
+    constexpr bool PHASED = (NW == 8) && (NQ >= 2) && (ARTMIPS_PHASED != 0);   // see below
+    constexpr int NCH = (KSTEPS >= 24) ? ((NW == 8) ? ((NQ >= 2) ? (PHASED ? KSTEPS : 12) : 8) : (NQ >= 4) ? 6 : 4) : 1;
     constexpr int CH = KSTEPS / NCH;
+    constexpr int NBUF = PHASED ? 4 : 2;   // register buffers of CH k-steps of row fragments
     static_assert(KSTEPS % NCH == 0, "k-steps must split evenly into chunks");
     // query fragments j*KSTEPS+s < VB live in VGPRs, the others in AGPRs (asm path, NQ >= 2)
     constexpr int VB = (NW == 8) ? NQ * KSTEPS : (NQ <= 3) ? KSTEPS : KSTEPS + (KSTEPS * 3) / 8;
@@ -610,11 +635,19 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     constexpr bool ASM_PATH = (NQ >= 2);
     // refill issued between the MFMA chunks (mg_compute) instead of in one burst behind the barrier
     // (tried for the 4 x 4 shape too: one piece behind each of its six chunks was 5 % slower than the burst)
-    constexpr bool INLINE_DMA = (NW == 8);
+    // PHASED (8 waves, two per SIMD): the waves of the first half (role A) do a stage's non-MFMA work
+    // (refill DMA, LDS read requests, filter of the previous stage) in FRONT of their MFMAs, the waves of
+    // the second half (role B) BEHIND theirs (filter of this stage, refill DMA, and the first LDS read
+    // requests of the NEXT stage, which therefore has to have landed one barrier early).  Right after the
+    // barrier B's MFMAs run while A issues memory instructions, at the end A's run while B does; in between
+    // the two share the pipe.  With both waves in the same order (rounds 1-2) the pipe idled while both
+    // were outside their MFMAs and each wave got every second slot while both were inside.
+    static_assert(!PHASED || NSTAGE >= 4, "the phased loop gives one stage of look-ahead away");
+    constexpr bool INLINE_DMA = (NW == 8) && !PHASED;
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-        thr[j] = (MODE == MODE_FILTER) ? ((ablate & 63) ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
+        thr[j] = (MODE == MODE_FILTER) ? ((ablate & (63 | 512 | 1024 | 2048)) ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
     // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image
@@ -656,6 +689,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     auto walk_next = [&](TileWalk& t) __attribute__((always_inline)) -> long long {
         uint32_t tile = t.q * t_mult + t.r + t_add;
         tile = tile < t_last ? tile : t_last;
+        if (ablate & 1024) tile = (uint32_t)b & 7u;   // diagnostic build: every refill re-reads one L2-resident tile
         // (readfirstlane: the DMA takes its base from scalar registers, and hipcc must not move this
         // chain of uniform values to the vector unit)
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
@@ -721,8 +755,13 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (int t = 0; t < TOPT; ++t) gm[j][t] = -INFINITY;
     }
     // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
-    int2* const my_list = (MODE == MODE_FILTER)
-        ? lists_base + ((size_t)b * NQ * NT + tid) * (size_t)a.cap : nullptr;
+    // (rebuilt from the thread index at every use: kept in a register pair for the whole loop, the 8-wave
+    // shape spills it, and a reload from scratch waits for every DMA piece in flight)
+    auto my_list = [&]() __attribute__((always_inline)) -> int2* {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return lists_base + ((size_t)b * NQ * NT + (size_t)t) * (size_t)a.cap;
+    };
     const size_t list_stride = (size_t)NT * (size_t)a.cap;  // between column groups
     // Survivors are staged in LDS (SLOTS entries per lane and column group, behind the ring) and
     // copied to the lane's list in HBM only when the staging is full and at the end of the launch.
@@ -734,7 +773,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     int2* const stg = (int2*)(smem + NSTAGE * STAGE_BYTES);   // [NQ][SLOTS][NT]
     auto flush = [&](int j, int first, int last) __attribute__((always_inline)) {  // copy staged entries [first, last) to HBM
         for (int e = first; e < last; ++e)
-            if (e < a.cap) my_list[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * NT + tid];
+            if (e < a.cap) my_list()[j * list_stride + e] = stg[(j * SLOTS + (e % SLOTS)) * NT + tid];
     };
 
     // Filter (or pass-0 maxima) of one finished stage: acc[j][i] = score(row = tile*16 + g*4 + i,
@@ -765,7 +804,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                                 if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
                                 stg[(j * SLOTS + slot_e) * NT + tid] = make_int2(__float_as_int(acc[j][i]), (int)row);
                             } else if (cnt[j] < a.cap) {
-                                my_list[j * list_stride + cnt[j]] = make_int2(__float_as_int(acc[j][i]), (int)row);
+                                my_list()[j * list_stride + cnt[j]] = make_int2(__float_as_int(acc[j][i]), (int)row);
                             }
                             ++cnt[j];
                         }
@@ -802,12 +841,27 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         settle_queries<NQ, KSTEPS, VB, ASM_PATH, 0>(bq);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) asm volatile("" ::"v"(thr[j]));
+        // (role B reads stage 0 in front of iteration 0's barrier: every wave's prologue pieces have landed)
+        if constexpr (PHASED) asm volatile("s_barrier" ::: "memory");
+        const bool role_b = PHASED && wave_active && (w >= NW / 2);
 
         int slot = 0;
 #ifdef ARTMIPS_STAMPS_BUILD
         unsigned long long st[24];
         const bool stamp_wg = a.stamps != nullptr && blockIdx.x == 137u % gridDim.x;
 #endif
+        // The streaming loop, once per role: two loops of their own (a wave runs one of them) instead of
+        // one loop with the role tested inside, which left hipcc short of registers (26 spilled, and every
+        // reload of a spilled value waits for ALL the DMA pieces in flight).  Each iteration of either
+        // loop passes exactly one barrier.
+        auto stream = [&](auto role_tag) __attribute__((always_inline)) {
+        constexpr bool RB = decltype(role_tag)::value == 1;
+        // LDS addresses of this lane's four fragment columns in the current slot: carried from stage to
+        // stage (four adds) instead of rebuilt from four loop-invariant offsets, which would hold four more
+        // registers for the whole loop (the 8-wave shape has none to spare)
+        uint32_t base[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) base[m] = lds_base + (uint32_t)rd_off[m];
         for (long long it = 0; it < n_it; ++it) {
 #ifdef ARTMIPS_STAMPS_BUILD
             const bool stamp_now = stamp_wg && it == n_it / 2;
@@ -816,8 +870,14 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             unsigned long long* const st = nullptr;
 #endif
             ARTMIPS_STAMP(stamp_now, st, 0);
-            // this wave's pieces of stage `it` have landed; the barrier makes it true for all waves
-            wait_vmcnt<(NSTAGE - 2) * PPW>();
+            [[maybe_unused]] V af[NBUF][CH];   // multi-group path: row fragments, NBUF chunks in registers
+            if constexpr (RB) {
+                if (!(ablate & 8)) mg_load_first<NBUF, CH, 0, V>(af, base);
+            }
+            // this wave's pieces of stage `it` (phased: `it + 1`) have landed; the barrier makes it true
+            // for all waves
+            constexpr int AHEAD = NSTAGE - (PHASED ? 3 : 2);   // stages that may still be on their way
+            if (!(ablate & 512)) wait_vmcnt<AHEAD * PPW>();   // (512: refill issued, never waited for)
             ARTMIPS_STAMP(stamp_now, st, 1);
             if (!(ablate & 2)) asm volatile("s_barrier" ::: "memory");
             ARTMIPS_STAMP(stamp_now, st, 2);
@@ -844,9 +904,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             // instead of in front of them, -0.7 % on one box and +2.9 % on another; and the first row
             // fragments of a stage requested before its wait and barrier, with one stage less of
             // look-ahead: +-0.5 % in the gang shapes)
-            if (!dma.on && !(ablate & 1)) issue_stage();
+            if (!dma.on && !RB && !(ablate & 1)) issue_stage();
             ARTMIPS_STAMP(stamp_now, st, 3);
-            fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
 
             if (wave_active) {
                 const char* sb = smem + slot * STAGE_BYTES;
@@ -880,19 +939,27 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 } else {
                     // chunks of CH k-steps, row fragments double-buffered in registers; the filter of
                     // the PREVIOUS stage runs inside, behind the first LDS read requests (mg_compute)
-                    V af[2][CH];
-                    uint32_t base[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) base[m] = lds_base + (uint32_t)(slot * STAGE_BYTES + rd_off[m]);
                     auto pre = [&]() __attribute__((always_inline)) {
                         if (it > 0) {
                             mg_settle_short<NQ, 0>(acc);
                             epilogue(it - 1, acc);
                         }
                     };
-                    mg_compute<T, NQ, KSTEPS, VB, NCH, CH, AUX, PPW, NW, 0, V>(acc, af, bq, base, dma, pre);
+                    if constexpr (RB) {
+                        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, NBUF, AUX, PPW, NW, 0, 1, V>(acc, af, bq, base, dma, pre);
+                        ARTMIPS_STAMP(stamp_now, st, 4);
+                        mg_settle<NQ, 0>(acc);
+                        epilogue(it, acc);
+                        ARTMIPS_STAMP(stamp_now, st, 5);
+                    } else {
+                        mg_compute<T, NQ, KSTEPS, VB, NCH, CH, NBUF, AUX, PPW, NW, 0, 0, V>(acc, af, bq, base, dma, pre);
+                    }
                 }
             }
+            if constexpr (RB) {
+                if (!(ablate & 1)) issue_stage();
+            }
+            fill_slot = (fill_slot + 1 == NSTAGE) ? 0 : fill_slot + 1;
             ARTMIPS_STAMP(stamp_now, st, 20);
 #ifdef ARTMIPS_STAMPS_BUILD
             if (stamp_now) {
@@ -900,17 +967,29 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 if (lane == 0) {
 #pragma unroll
                     for (int i = 0; i < 24; ++i)
-                        a.stamps[w * 24 + i] = (i <= 5 || i == 20 || (i >= 6 && i < 6 + NCH)) ? st[i] : 0ull;
+                        a.stamps[w * 24 + i] = (i <= 5 || i == 20 || (i >= 6 && i < 6 + (NCH > 12 ? 12 : NCH))) ? st[i] : 0ull;
                 }
             }
 #endif
+            {
+                const uint32_t step = (slot + 1 == NSTAGE) ? (uint32_t)(-(NSTAGE - 1) * STAGE_BYTES) : (uint32_t)STAGE_BYTES;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) base[m] += step;
+            }
             slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
         }
-        if constexpr (NQ > 1) {
+        if constexpr (NQ > 1 && !RB) {
             if (wave_active) {   // the last stage's filter (every other stage's ran inside the next one)
                 mg_settle<NQ, 0>(acc);
                 epilogue(n_it - 1, acc);
             }
+        }
+        };
+        if constexpr (PHASED) {
+            if (role_b) stream(std::integral_constant<int, 1>());
+            else stream(std::integral_constant<int, 0>());
+        } else {
+            stream(std::integral_constant<int, 0>());
         }
         // the tail DMAs (clamped re-reads) must land before the workgroup's LDS is released
         wait_vmcnt<0>();

@@ -59,8 +59,8 @@ for r in range(rounds):
         wall[name].append((time.perf_counter() - t0) * 1e3)
         scan[name].append(eng.info()["last_scan_ms"])
 info = eng.info()
-print("rows %d Q %d k %d %s, %d scan launches per call, %d rounds" % (rows, nq, k, sys.argv[4],
-                                                                       info["last_scan_launches"], rounds))
+print("rows %d Q %d k %d %s, %d scan launches per call, %d rounds, %d candidates kept by the last call's filter" % (
+    rows, nq, k, sys.argv[4], info["last_scan_launches"], rounds, info["last_candidates"]))
 for name, val in arms:
     print("  %-22s ablate %-4s scan median %.3f min %.3f ms | call median %.3f min %.3f ms" % (
         name, val, statistics.median(scan[name]), min(scan[name]), statistics.median(wall[name]), min(wall[name])))
