@@ -196,7 +196,9 @@ struct ScanArgs {
                           // parts of the loop off (results are then meaningless): 1 = no refill DMA, 2 = no
                           // barrier, 4 = no compute, 8 = no LDS reads, 16 = no filter, 32 = reads never waited
                           // for.  Bits 64..256 select code variants with identical results, for A/B runs in one
-                          // process: 64 = DMA pieces one by one, 256 = no one-branch pre-check in the filter
+                          // process: 64 = DMA pieces one by one, 256 = no one-branch pre-check in the filter.
+                          // Again meaningless results: 512 = refill issued but never waited for, 1024 = every refill
+                          // re-reads one tile (served by the CU's vector L1), 2048 = threshold +inf and nothing else
 };
 
 // LDS image of a stage (16 rows): the rows as they lie in memory (row-major, contiguous), cut into
@@ -643,6 +645,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // the two share the pipe.  With both waves in the same order (rounds 1-2) the pipe idled while both
     // were outside their MFMAs and each wave got every second slot while both were inside.
     static_assert(!PHASED || NSTAGE >= 4, "the phased loop gives one stage of look-ahead away");
+    // (the phased loop issues its refill in two bursts, role A's behind the barrier and role B's at the end of
+    // the stage; with the pieces riding inside the stretches where a wave computes alone it was 4 % slower:
+    // profiles/r03_d_phased_ab.txt)
     constexpr bool INLINE_DMA = (NW == 8) && !PHASED;
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
