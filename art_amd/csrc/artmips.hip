@@ -1072,6 +1072,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     sa.done_counter = ws.status + 8;   // word 8 of the shard's own status block (zeroed when allocated)
 
     a.ablate = diag_int("ARTMIPS_ABLATE", 0);  // diagnostic build only: results are then meaningless
+    a.thr_shift = 0.01f * (float)diag_int("ARTMIPS_THR_SHIFT", 0);
     if (timed) {
         while ((int)s.ev_scan.size() < 2 * (tile_index + 1)) {
             hipEvent_t e;

@@ -192,6 +192,8 @@ struct ScanArgs {
     int counts_continue;
     unsigned long long* stamps;  // diagnostic build only (ARTMIPS_STAMPS): [8 waves][24] shader-clock stamps of one
                                  // iteration of one workgroup (see ARTMIPS_STAMP in scan_kernel); NULL = off
+    float thr_shift;      // diagnostic build only (ARTMIPS_THR_SHIFT, in 1/100): added to every threshold, to see how the
+                          // scan time follows the number of survivors (results are then incomplete)
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE).  Bits 1..32 switch
                           // parts of the loop off (results are then meaningless): 1 = no refill DMA, 2 = no
                           // barrier, 4 = no compute, 8 = no LDS reads, 16 = no filter, 32 = reads never waited
@@ -585,8 +587,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const int g = lane >> 4;  // MFMA k-group of this lane
 #ifdef ARTMIPS_DIAG
     const int ablate = a.ablate;   // timing experiments of the diagnostic build
+    const float thr_shift = a.thr_shift;
 #else
     constexpr int ablate = 0;      // the shipped library has no ablation code
+    constexpr float thr_shift = 0.0f;
 #endif
     // ---- which tiles, which queries (gang mode: see ScanArgs)
     long long b = blockIdx.x;       // logical workgroup index: tiles b, b + grid, ...
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     load_queries<T, NQ, KSTEPS, VB, ASM_PATH, QG, 0>(bq, qbase, w * 16 + r, q_rows, g);
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-        thr[j] = (MODE == MODE_FILTER) ? ((ablate & (63 | 512 | 1024 | 2048)) ? INFINITY : thr_base[j * QG + w * 16 + r]) : 0.0f;
+        thr[j] = (MODE == MODE_FILTER) ? ((ablate & (63 | 512 | 1024 | 2048)) ? INFINITY : thr_base[j * QG + w * 16 + r] + thr_shift) : 0.0f;
     // (these loads are drained below, together with the DMA prologue that is issued behind them)
 
     // ---- per-lane constants of the LDS image

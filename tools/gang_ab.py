@@ -5,7 +5,7 @@ results are identical, which is checked), interleaved round by round so that clo
 drawn hit all arms alike.
 
 usage: ARTMIPS_DIAGNOSTICS=1 ARTMIPS_LIBRARY=.../libartmips_diag.so python tools/gang_ab.py ROWS Q K DTYPE ROUNDS ARM [ARM ...]
-       an ARM is an ARTMIPS_ABLATE value, optionally name=value
+       an ARM is an ARTMIPS_ABLATE value, optionally name=value; value/shift also sets ARTMIPS_THR_SHIFT (1/100)
 prints per arm: median / min of the summed scan-kernel time of a call (HIP events) and of the whole call.
 """
 import os
@@ -38,8 +38,15 @@ time.sleep(float(os.environ.get("GANG_AB_SETTLE", "6")))
 ref = None
 scan = {n: [] for n, _ in arms}
 wall = {n: [] for n, _ in arms}
+def select(val):
+    ab, _, shift = val.partition("/")
+    os.environ["ARTMIPS_ABLATE"] = ab
+    os.environ["ARTMIPS_THR_SHIFT"] = shift or "0"
+
+
+cands = {}
 for name, val in arms:  # warm every arm (first-use attribute calls, buffer growth, clock ramp)
-    os.environ["ARTMIPS_ABLATE"] = val
+    select(val)
     for _ in range(2):
         s, i = eng.search(q, k)
     if ref is None:
@@ -51,17 +58,19 @@ for name, val in arms:  # warm every arm (first-use attribute calls, buffer grow
 for r in range(rounds):
     order = arms if r % 2 == 0 else arms[::-1]
     for name, val in order:
-        os.environ["ARTMIPS_ABLATE"] = val
+        select(val)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.search(q, k)
         torch.cuda.synchronize()
         wall[name].append((time.perf_counter() - t0) * 1e3)
         scan[name].append(eng.info()["last_scan_ms"])
+        cands[name] = eng.info()["last_candidates"]
 info = eng.info()
 print("rows %d Q %d k %d %s, %d scan launches per call, %d rounds, %d candidates kept by the last call's filter" % (
     rows, nq, k, sys.argv[4], info["last_scan_launches"], rounds, info["last_candidates"]))
 for name, val in arms:
-    print("  %-22s ablate %-4s scan median %.3f min %.3f ms | call median %.3f min %.3f ms" % (
-        name, val, statistics.median(scan[name]), min(scan[name]), statistics.median(wall[name]), min(wall[name])))
+    print("  %-22s ablate %-4s scan median %.3f min %.3f ms | call median %.3f min %.3f ms | %d candidates" % (
+        name, val, statistics.median(scan[name]), min(scan[name]), statistics.median(wall[name]), min(wall[name]),
+        cands[name]))
 eng.close()
