@@ -96,6 +96,7 @@ struct Shard {
     std::vector<hipEvent_t> ev_scan;                   // pairs around each FILTER scan
     // workspace
     DevBuf qpad, thr, gmax, counts, lists, keys, status, qin, loc_scores, loc_ids, loc_packed;
+    unsigned gang_epoch = 0;   // gang rendezvous: changes with every FILTER launch (ScanArgs::gang_epoch)
     int* status_host = nullptr;  // pinned mirror of status[4] (+ cand_total as 2 ints), written by the
                                  // last select launch of a search itself (SelectArgs::publish)
     int* status_host_dev = nullptr;  // the same words as the device sees them
@@ -831,6 +832,10 @@ extern "C" int artmips_finalize(artmips_t* h) {
 // ---------------------------------------------------------------------------------------------
 // per-shard search pipeline
 // ---------------------------------------------------------------------------------------------
+// a shard's status block: 16 status words, then (at STATUS_SYNC_OFFSET) the gang rendezvous' progress words,
+// 8 per logical workgroup of a gang launch (at most n_cu / 2 of them)
+constexpr size_t STATUS_SYNC_OFFSET = 256;
+constexpr size_t STATUS_BLOCK_BYTES = STATUS_SYNC_OFFSET + 256 * 8 * 4;
 constexpr int STATUS_UNPUBLISHED = -1;   // never a value of the flag word (bits 0 and 1 only)
 
 struct Plan {
@@ -1071,6 +1076,9 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     sa.publish = publish ? s.status_host_dev : nullptr;
     sa.done_counter = ws.status + 8;   // word 8 of the shard's own status block (zeroed when allocated)
 
+    // gang rendezvous: the progress words live behind the status words of the same block
+    a.gang_progress = (p.gang > 1) ? (unsigned int*)((char*)ws.status + STATUS_SYNC_OFFSET) : nullptr;
+    a.sync_lead = diag_int("ARTMIPS_SYNC_LEAD", 0);   // diagnostic build only
     a.ablate = diag_int("ARTMIPS_ABLATE", 0);  // diagnostic build only: results are then meaningless
     a.thr_shift = 0.01f * (float)diag_int("ARTMIPS_THR_SHIFT", 0);
     if (timed) {
@@ -1087,6 +1095,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         const long long part_a = (p.n_tiles + p.refine - 1) / p.refine;
         a.n_work = part_a;
         a.tile_stride = p.refine;
+        a.gang_epoch = (++s.gang_epoch) & 0xFFFu;
         if ((rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid * p.gang, st))) return rc;
         DEBUG_STEP(st, "scan<FILTER> part A grid=%d tiles=%lld", p.grid * p.gang, a.n_work);
         // thr[q] <- max(thr[q], k-th best score among the survivors of part A)
@@ -1116,6 +1125,7 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
         a.stamps = stamp_buf;
     }
 #endif
+    a.gang_epoch = (++s.gang_epoch) & 0xFFFu;
     rc = launch_scan(h->dtype, h->dim, p.nq, p.nw, p.stage_lds, MODE_FILTER, a, p.grid * p.gang, st);
     if (rc) return rc;
 #ifdef ARTMIPS_STAMPS_BUILD
@@ -1267,7 +1277,7 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
             off += (bytes + 255) & ~(size_t)255;
             return at;
         };
-        ws.status = (int*)take(64);
+        ws.status = (int*)take(STATUS_BLOCK_BYTES);
         ws.thr = (float*)take(sz_thr);
         ws.qpad = take(sz_qpad);
         ws.gmax = (float*)take(sz_gmax);
@@ -1287,10 +1297,10 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
         if ((rc = ensure(s.qpad, sz_qpad))) return rc;
         if ((rc = ensure(s.thr, sz_thr))) return rc;
         if (!s.status.p) {
-            if ((rc = ensure(s.status, 64))) return rc;
+            if ((rc = ensure(s.status, STATUS_BLOCK_BYTES))) return rc;
             // word 8 is select_kernel's done counter; zeroed on the stream the pipeline runs on (the
             // null stream orders nothing against a non-blocking stream)
-            HIP_TRY(hipMemsetAsync(s.status.p, 0, 64, c.st));
+            HIP_TRY(hipMemsetAsync(s.status.p, 0, STATUS_BLOCK_BYTES, c.st));
         }
         if (sz_gmax && (rc = ensure(s.gmax, sz_gmax))) return rc;
         if ((rc = ensure(s.counts, sz_counts))) return rc;

@@ -52,6 +52,9 @@ enum { MODE_FILTER = 0, MODE_GROUPMAX = 1 };
 #define ARTMIPS_MFMA_PAD "s_nop 1\n\t"
 #endif
 
+#ifndef ARTMIPS_GANG_SYNC
+#define ARTMIPS_GANG_SYNC 1   // 0: no rendezvous between the members of a gang (A/B builds only)
+#endif
 #ifndef ARTMIPS_PHASED
 #define ARTMIPS_PHASED 1   // 0: the 8-wave loop of rounds 1-2 (A/B builds only)
 #endif
@@ -192,6 +195,11 @@ struct ScanArgs {
     int counts_continue;
     unsigned long long* stamps;  // diagnostic build only (ARTMIPS_STAMPS): [8 waves][24] shader-clock stamps of one
                                  // iteration of one workgroup (see ARTMIPS_STAMP in scan_kernel); NULL = off
+    // Gang rendezvous (8-wave gang kernels): one progress word per gang member, [logical workgroup][8], value
+    // (epoch << 20) | stage; NULL = off.  Words of other launches (other epochs) read as "not started".
+    unsigned int* gang_progress;
+    unsigned int gang_epoch;   // 12 bits, changes with every launch that shares the words
+    int sync_lead;             // stages a member may be ahead of the slowest before it pauses (0 = default)
     float thr_shift;      // diagnostic build only (ARTMIPS_THR_SHIFT, in 1/100): added to every threshold, to see how the
                           // scan time follows the number of survivors (results are then incomplete)
     int ablate;           // read by the diagnostic build only (-DARTMIPS_DIAG, ARTMIPS_ABLATE).  Bits 1..32 switch
@@ -274,6 +282,14 @@ __device__ __forceinline__ void glds16_piece(const void* base, uint32_t voff, ui
     else
         asm volatile(ARTMIPS_GLDS_HEAD "global_load_lds_dwordx4 %3, %2 offset:%4\n\t" ARTMIPS_GLDS_TAIL
                      : "=&s"(keep) : "s"(m0_val), "s"(base), "v"(voff), "n"(OFF) : "memory");
+}
+// One dword per lane into LDS, read at device scope (past the CU's vector L1): the gang rendezvous reads the
+// other members' progress words with it.  A DMA, not a register load: a register load would have to be
+// waited for, and vmcnt retires in order, i.e. behind every refill piece in flight.
+__device__ __forceinline__ void glds4_device_scope(const void* base, uint32_t voff, uint32_t dst) {
+    uint32_t keep;
+    asm volatile(ARTMIPS_GLDS_HEAD "global_load_lds_dword %3, %2 sc0 sc1\n\t" ARTMIPS_GLDS_TAIL
+                 : "=&s"(keep) : "s"(dst), "s"(base), "v"(voff) : "memory");
 }
 // diagnostic build (ARTMIPS_ABLATE & 64): the pieces of a stage one by one, each with its own M0 round trip
 template <int AUX, int PPW, int GS, int PP>
@@ -853,6 +869,30 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         // (role B reads stage 0 in front of iteration 0's barrier: every wave's prologue pieces have landed)
         if constexpr (PHASED) asm volatile("s_barrier" ::: "memory");
         const bool role_b = PHASED && wave_active && (w >= NW / 2);
+        // Gang rendezvous.  The members of a gang share their tiles through L2 only while they are within
+        // a few dozen stages of each other, and nothing kept them there: a member whose queries meet fewer
+        // survivors runs ahead, the ring's look-ahead hides its misses from it, and at top-1000 the shard
+        // came from HBM 3.6 times per sweep (L2 hit rate 0.53 where lock-step gives 0.875:
+        // profiles/r03_e_gang_sync.txt).  So every fourth (8 waves) or eighth (4 waves) stage wave 0 of a
+        // member publishes its stage number and asks for the members' words with a DMA into LDS; one period
+        // later, when the counted wait has covered that DMA anyway, it looks at them and pauses (bounded: two
+        // s_sleep at most, whatever the others do) if somebody is more than `sync_lead` stages behind (what it
+        // sees is one to two periods old, so the lead must exceed that: with 8 the 4-wave shape pauses all the
+        // time, 16 and 32 measure alike).
+        constexpr bool GANG_SYNC = (AUX == 0) && (NQ >= 2) && (STG == 0) && (MODE == MODE_FILTER) && (ARTMIPS_GANG_SYNC != 0);
+        // (period in stages: with two waves per SIMD the few instructions hide behind the partner's MFMAs; a lone
+        // wave pays for them.  The request is covered by the counted wait `period` stages later as long as the
+        // period is not shorter than the ring's look-ahead.)
+        constexpr int SYNC_SHIFT = (NW == 8) ? 2 : 3;
+        static_assert(!GANG_SYNC || (1 << SYNC_SHIFT) >= NSTAGE - (PHASED ? 3 : 2), "rendezvous period shorter than the look-ahead");
+        constexpr uint32_t SYNC_LDS = (uint32_t)(NSTAGE * STAGE_BYTES);   // the staging area (unused: STG == 0)
+        const bool sync_on = GANG_SYNC && w == 0 && a.gang > 1 && a.gang_progress != nullptr && !(ablate & 8192);
+        const unsigned int* sync_words = nullptr;
+        uint32_t sync_lead = 0;
+        if constexpr (GANG_SYNC) {
+            sync_words = a.gang_progress + (size_t)__builtin_amdgcn_readfirstlane((int)(b * 8));
+            sync_lead = a.sync_lead > 0 ? (uint32_t)a.sync_lead : (NW == 8 ? 16u : 24u);
+        }
 
         int slot = 0;
 #ifdef ARTMIPS_STAMPS_BUILD
@@ -913,6 +953,33 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             // instead of in front of them, -0.7 % on one box and +2.9 % on another; and the first row
             // fragments of a stage requested before its wait and barrier, with one stage less of
             // look-ahead: +-0.5 % in the gang shapes)
+            if constexpr (GANG_SYNC && !RB) {
+                if (sync_on && (it & ((1 << SYNC_SHIFT) - 1)) == 0) {
+                    if (it >= (1 << SYNC_SHIFT)) {
+                        // (asm: through a generic pointer hipcc reads LDS with a flat load and waits vmcnt(0))
+                        uint32_t v;
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=v"(v)
+                                     : "v"(lds_base + SYNC_LDS + (uint32_t)(((it >> SYNC_SHIFT) - 1) & 7) * 256u + (uint32_t)(lane & 7) * 4u)
+                                     : "memory");
+                        // a member counts while it runs in this launch and is not hopelessly far behind (one that
+                        // has not started, or started late because the GPU is shared, is not waited for)
+                        const uint32_t peer = v & 0xFFFFFu;
+                        const bool counts = (lane & 7) < a.gang && (v >> 20) == a.gang_epoch && (uint32_t)it < peer + 256u;
+                        if (__builtin_amdgcn_ballot_w64(counts && (uint32_t)it > peer + sync_lead) != 0ull) {
+                            __builtin_amdgcn_s_sleep(127);
+                            if (__builtin_amdgcn_ballot_w64(counts && (uint32_t)it > peer + 2 * sync_lead) != 0ull)
+                                __builtin_amdgcn_s_sleep(127);
+                        }
+                    }
+                    if (lane == 0)
+                        __hip_atomic_store(const_cast<unsigned int*>(sync_words) + (blockIdx.x >> 3) % a.gang,
+                                           (a.gang_epoch << 20) | (uint32_t)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    glds4_device_scope(sync_words, (uint32_t)(lane & 7) * 4u,
+                                       (uint32_t)__builtin_amdgcn_readfirstlane(
+                                           (int)(lds_base + SYNC_LDS + (uint32_t)((it >> SYNC_SHIFT) & 7) * 256u)));
+                }
+            }
             if (!dma.on && !RB && !(ablate & 1)) issue_stage();
             ARTMIPS_STAMP(stamp_now, st, 3);
 

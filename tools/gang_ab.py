@@ -5,7 +5,7 @@ results are identical, which is checked), interleaved round by round so that clo
 drawn hit all arms alike.
 
 usage: ARTMIPS_DIAGNOSTICS=1 ARTMIPS_LIBRARY=.../libartmips_diag.so python tools/gang_ab.py ROWS Q K DTYPE ROUNDS ARM [ARM ...]
-       an ARM is an ARTMIPS_ABLATE value, optionally name=value; value/shift also sets ARTMIPS_THR_SHIFT (1/100)
+       an ARM is an ARTMIPS_ABLATE value, optionally name=value; value/shift/lead also sets ARTMIPS_THR_SHIFT (1/100) and ARTMIPS_SYNC_LEAD
 prints per arm: median / min of the summed scan-kernel time of a call (HIP events) and of the whole call.
 """
 import os
@@ -39,9 +39,10 @@ ref = None
 scan = {n: [] for n, _ in arms}
 wall = {n: [] for n, _ in arms}
 def select(val):
-    ab, _, shift = val.partition("/")
-    os.environ["ARTMIPS_ABLATE"] = ab
-    os.environ["ARTMIPS_THR_SHIFT"] = shift or "0"
+    parts = (val.split("/") + ["", ""])[:3]
+    os.environ["ARTMIPS_ABLATE"] = parts[0]
+    os.environ["ARTMIPS_THR_SHIFT"] = parts[1] or "0"
+    os.environ["ARTMIPS_SYNC_LEAD"] = parts[2] or "0"
 
 
 cands = {}
