@@ -1233,7 +1233,9 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
             if (max_gang >= 8 && left > 7 * 256) gang = 8;
             else if (max_gang >= 4 && left > 3 * 256) gang = 4;
             else if (max_gang >= 2 && left > 256 + 128) gang = 2;
-            if (gang > 1 && nw_knob != 88 && (c.k <= 128 || nw_knob == 44)) {
+            // (4 x 4 up to k = 256: 1 % ahead of 8 x 2 at k = 200, level at 300, 1.4 % behind at 500, 6 % at 1,000:
+            // profiles/r03_e_gang_sync.txt)
+            if (gang > 1 && nw_knob != 88 && (c.k <= 256 || nw_knob == 44)) {
                 nw = 4;
                 nq = 4;
             } else {

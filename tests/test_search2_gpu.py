@@ -73,6 +73,9 @@ def test_k2048_integer_ties_with_pass0(gu):
     (70000, 1100, 500, "f16"),    # gang of 4 + 76 queries; two-part scan with threshold refinement
     (300000, 300, 1000, "f16"),   # 8 x 2 without a gang, two-part scan, + 44 queries
     (36000, 450, 50, "f16"),      # gang of 2 with 194 queries in the second member, small shard
+    (70000, 1024, 200, "f16"),    # gang of 4 in the 4 x 4 shape at 128 < k <= 256 (top-4 pass 0, two-part scan)
+    (40000, 2100, 256, "bf16"),   # gang of 8 in the 4 x 4 shape at k = 256 + 52 queries
+    (40000, 2048, 257, "bf16"),   # first k of the 8 x 2 shape
 ])
 def test_gang_launches_vs_oracle(gu, n, q, k, storage):
     rng = np.random.Generator(np.random.PCG64(5000 + n + q))
