@@ -1252,6 +1252,9 @@ static int shard_enqueue(artmips* h, ShardCall& c) {
                                       nw, h->dim == 768 && h->dtype != ARTMIPS_F32, gang);
             have[slot_i] = true;
             const Plan& p = cache[slot_i];
+            // (the scan kernels address a lane's list entries with a 32-bit byte offset inside its column group)
+            if ((unsigned long long)nw * 64ull * (unsigned long long)p.cap * 8ull >= (1ull << 32))
+                return fail(ARTMIPS_ERR_UNSUPPORTED, "internal: candidate lists of %d entries per lane", p.cap);
             const size_t QT = (size_t)nq * nw * 16 * gang, NT = (size_t)nw * 64;
             sz_qpad = std::max(sz_qpad, QT * h->dim * elem_size(h->dtype));
             sz_thr = std::max(sz_thr, QT * 4);

@@ -208,7 +208,8 @@ struct ScanArgs {
                           // for.  Bits 64..256 select code variants with identical results, for A/B runs in one
                           // process: 64 = DMA pieces one by one, 256 = no one-branch pre-check in the filter.
                           // Again meaningless results: 512 = refill issued but never waited for, 1024 = every refill
-                          // re-reads one tile (served by the CU's vector L1), 2048 = threshold +inf and nothing else
+                          // re-reads one tile (served by the CU's vector L1), 2048 = threshold +inf and nothing else,
+                          // 16384 = survivors found and counted but not stored; 8192 = no gang rendezvous (results valid)
 };
 
 // LDS image of a stage (16 rows): the rows as they lie in memory (row-major, contiguous), cut into
@@ -725,14 +726,27 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         return (long long)tile;
     };
     TileWalk walk_issue{t_q0, t_r0};      // stages are issued in order: prologue, then one per iteration
-    // the filter asks for a stage's tile only when the stage has survivors: direct formula there
+    // the filter asks for a stage's tile only when the stage has survivors: direct formula there, without
+    // branches (the slow path is on the critical path of its workgroup): wk / d by a multiply-high with a
+    // 32-bit magic number that is exact for every 32-bit wk (d = 3: 0xAAAAAAAB >> 33, d = 7: 0x92492493 >> 34),
+    // and tile = q * (d + 1) + (wk - q * d) + 1; without a skip the magic is 0, so q = 0 and tile = wk * stride
+    // (8-wave kernels only: the 4-wave shapes keep the branching form below; with the branch-free one the 4 x 4
+    // gang scan measured 1.7 % slower, the 8 x 2 one 1.6 % faster: profiles/r03_f_slow_path.txt)
     auto tile_of = [&](long long wk) __attribute__((always_inline)) -> long long {
-        if (a.tile_skip) {
+        if constexpr (NW == 8) {
+            const uint32_t td_magic = a.tile_skip == 8 ? 0x92492493u : a.tile_skip ? 0xAAAAAAABu : 0u;
+            const uint32_t td_shift = a.tile_skip == 8 ? 2u : 1u;
             const uint32_t w32 = (uint32_t)wk;
-            return (a.tile_skip == 8) ? (long long)((w32 / 7u) * 8u + w32 % 7u + 1u)
-                                      : (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
+            const uint32_t qq = (uint32_t)(((unsigned long long)w32 * td_magic) >> 32) >> td_shift;
+            return (long long)(qq * t_mult + (w32 - qq * t_mod) * (a.tile_skip ? 1u : t_mult) + t_add);
+        } else {
+            if (a.tile_skip) {
+                const uint32_t w32 = (uint32_t)wk;
+                return (a.tile_skip == 8) ? (long long)((w32 / 7u) * 8u + w32 % 7u + 1u)
+                                          : (long long)((w32 / 3u) * 4u + w32 % 3u + 1u);
+            }
+            return wk * stride;
         }
-        return wk * stride;
     };
 
     // byte offset, inside a tile, of the 16-byte chunk that lane `lane` fetches for its pp-th piece
@@ -782,6 +796,11 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // list of (b, group j, tid) starts at ((b*NQ + j)*256 + tid) * cap
     // (rebuilt from the thread index at every use: kept in a register pair for the whole loop, the 8-wave
     // shape spills it, and a reload from scratch waits for every DMA piece in flight)
+    auto lane_id_opaque = [&]() __attribute__((always_inline)) -> int {   // thread index, not hoisted out of the loop
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
     auto my_list = [&]() __attribute__((always_inline)) -> int2* {
         int t = tid;
         asm volatile("" : "+v"(t));
@@ -812,7 +831,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             }
         }
         // (only a stage with survivors, and pass 0, need to know which rows these are)
-        const long long row_base = tile_of(b + it_e * grid) * TILE_ROWS + g * 4;
+        // (rows fit 31 bits: 32-bit row arithmetic and compares in the slow path)
+        const int row_base = (int)(tile_of(b + it_e * grid) * TILE_ROWS) + g * 4;
+        const int n_rows32 = (int)n_rows;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (ablate & 16) {
@@ -822,14 +843,27 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 if (__builtin_amdgcn_ballot_w64(m >= thr[j]) != 0ull) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const long long row = row_base + i;
-                        if (acc[j][i] >= thr[j] && row < n_rows) {
+                        const int row = row_base + i;
+                        if (acc[j][i] >= thr[j] && row < n_rows32) {
                             if (STG) {
                                 const int slot_e = cnt[j] % SLOTS;
                                 if (slot_e == 0 && cnt[j] > 0) flush(j, cnt[j] - SLOTS, cnt[j]);
                                 stg[(j * SLOTS + slot_e) * NT + tid] = make_int2(__float_as_int(acc[j][i]), (int)row);
-                            } else if (cnt[j] < a.cap) {
-                                my_list()[j * list_stride + cnt[j]] = make_int2(__float_as_int(acc[j][i]), (int)row);
+                            } else if (!(ablate & 16384)) {   // (16384: everything but the store)
+                                // uniform base of this (workgroup, column group)'s lists + a 32-bit lane offset:
+                                // one multiply-add instead of 64-bit pointer arithmetic per survivor
+                                char* const lb = (char*)(lists_base + ((size_t)b * NQ + j) * list_stride);
+                                if constexpr (NW == 8) {
+                                    // a full list takes the entry in its last slot instead of testing for room:
+                                    // the count runs on, and a count above the capacity reports the overflow
+                                    // (8 waves only: the 4 x 4 shape measured 0.6 % slower with it)
+                                    const uint32_t at = min((uint32_t)cnt[j], (uint32_t)a.cap - 1u);
+                                    *(int2*)(lb + ((uint32_t)lane_id_opaque() * (uint32_t)a.cap + at) * 8u) =
+                                        make_int2(__float_as_int(acc[j][i]), row);
+                                } else if (cnt[j] < a.cap) {
+                                    *(int2*)(lb + ((uint32_t)lane_id_opaque() * (uint32_t)a.cap + (uint32_t)cnt[j]) * 8u) =
+                                        make_int2(__float_as_int(acc[j][i]), row);
+                                }
                             }
                             ++cnt[j];
                         }
@@ -838,9 +872,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const long long row = row_base + i;
+                    const int row = row_base + i;
                     // insertion into the lane's descending top-TOPT (NaN never enters)
-                    float x = (row < n_rows) ? acc[j][i] : -INFINITY;
+                    float x = (row < n_rows32) ? acc[j][i] : -INFINITY;
 #pragma unroll
                     for (int t = 0; t < TOPT; ++t) {
                         const float hi = fmaxf(gm[j][t], x);
