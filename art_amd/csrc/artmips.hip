@@ -1077,7 +1077,8 @@ static int enqueue_tile(artmips* h, Shard& s, const Workspace& ws, const Plan& p
     sa.done_counter = ws.status + 8;   // word 8 of the shard's own status block (zeroed when allocated)
 
     // gang rendezvous: the progress words live behind the status words of the same block
-    a.gang_progress = (p.gang > 1) ? (unsigned int*)((char*)ws.status + STATUS_SYNC_OFFSET) : nullptr;
+    // (256 logical workgroups have words there; a larger grid, which only a diagnostic knob produces, runs without)
+    a.gang_progress = (p.gang > 1 && p.grid <= 256) ? (unsigned int*)((char*)ws.status + STATUS_SYNC_OFFSET) : nullptr;
     a.sync_lead = diag_int("ARTMIPS_SYNC_LEAD", 0);   // diagnostic build only
     a.ablate = diag_int("ARTMIPS_ABLATE", 0);  // diagnostic build only: results are then meaningless
     a.thr_shift = 0.01f * (float)diag_int("ARTMIPS_THR_SHIFT", 0);
