@@ -929,7 +929,10 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
         // LDS staging holds 8/nq survivors per lane and column group; it pays while a lane flushes
         // at most a few times per launch (profiles/r01_j_lds_staging_ab.txt)
         // (8 waves x 2 groups has no registers left for the staging bookkeeping: it would spill in the loop)
-        p.stage_lds = !(nw == 8 && nq == 2) && per_list <= 4.0 * staging_slots;
+        // (gang launches always write their lists directly: the staging area is where their rendezvous keeps
+        // its words, a two-part scan needs direct writes, and staged gangs measured 0-4 % slower:
+        // profiles/r03_e_gang_sync.txt)
+        p.stage_lds = gang == 1 && !(nw == 8 && nq == 2) && per_list <= 4.0 * staging_slots;
         p.refine = period;
     };
     // Where the lists are written directly (many survivors per lane: large k, or large batches at any

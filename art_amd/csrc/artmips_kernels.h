@@ -925,7 +925,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         uint32_t sync_lead = 0;
         if constexpr (GANG_SYNC) {
             sync_words = a.gang_progress + (size_t)__builtin_amdgcn_readfirstlane((int)(b * 8));
-            sync_lead = a.sync_lead > 0 ? (uint32_t)a.sync_lead : (NW == 8 ? 16u : 24u);
+            // (16 everywhere but the 8-wave gangs of 2: sixteen of those share an XCD's L2, which then holds
+            // fewer stages per gang: profiles/r03_e_gang_sync.txt)
+            sync_lead = a.sync_lead > 0 ? (uint32_t)a.sync_lead : (NW == 8 && a.gang <= 2 ? 8u : 16u);
         }
 
         int slot = 0;
