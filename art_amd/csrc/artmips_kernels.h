@@ -728,7 +728,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     TileWalk walk_issue{t_q0, t_r0};      // stages are issued in order: prologue, then one per iteration
     // the filter asks for a stage's tile only when the stage has survivors: direct formula there, without
     // branches (the slow path is on the critical path of its workgroup): wk / d by a multiply-high with a
-    // 32-bit magic number that is exact for every 32-bit wk (d = 3: 0xAAAAAAAB >> 33, d = 7: 0x92492493 >> 34),
+    // 32-bit magic number (d = 3: 0xAAAAAAAB >> 33, exact for every 32-bit wk; d = 7: 0x92492493 >> 34, exact below
+    // 2^34 / 5 = 3.4e9; work indices are tile counts, below 2^27: tests/test_tile_formula_cpu.py),
     // and tile = q * (d + 1) + (wk - q * d) + 1; without a skip the magic is 0, so q = 0 and tile = wk * stride
     // (8-wave kernels only: the 4-wave shapes keep the branching form below; with the branch-free one the 4 x 4
     // gang scan measured 1.7 % slower, the 8 x 2 one 1.6 % faster: profiles/r03_f_slow_path.txt)
