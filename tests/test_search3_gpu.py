@@ -165,6 +165,52 @@ print("remote ok")
     assert r.returncode == 0 and "remote ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_gang_rendezvous_changes_timing_only():
+    """The rendezvous between the members of a gang (scan_kernel GANG_SYNC) only ever pauses a workgroup: the
+    diagnostic build switches it off (ARTMIPS_ABLATE 8192) and makes it pause all the time (a lead of 1 stage);
+    ids and scores must be bit-identical in all three, in both gang shapes (4 x 4 at top-100, 8 x 2 at top-1000),
+    through the two-part scan, and right by the oracle."""
+    code = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from art_amd import _lib
+assert _lib.LIB_PATH.endswith("libartmips_diag.so")
+from tests import gpu_util as gu
+from oracle import mips_oracle as orc
+
+rng = np.random.Generator(np.random.PCG64(8100))
+n = 140000   # enough tiles for gangs of 8 and for the two-part scan
+rows = (rng.standard_normal((n, 768)) * 0.05).astype(np.float16)
+ids = (rng.permutation(n) + 1).astype(np.int32)
+eng = gu.build_engine(rows, ids)
+for nq, k in ((2048, 100), (2048, 1000), (1024, 300)):
+    queries = rng.standard_normal((nq, 768)).astype(np.float16)
+    q = torch.from_numpy(queries).cuda()
+    out = []
+    for ablate, lead in (("0", "0"), ("8192", "0"), ("0", "1")):
+        os.environ["ARTMIPS_ABLATE"] = ablate
+        os.environ["ARTMIPS_SYNC_LEAD"] = lead
+        s, i = eng.search(q, k, score_dtype=torch.float32)
+        assert eng.info()["last_retries"] == 0
+        out.append((s, i))
+    os.environ["ARTMIPS_ABLATE"] = "0"
+    os.environ["ARTMIPS_SYNC_LEAD"] = "0"
+    for s, i in out[1:]:
+        assert torch.equal(i, out[0][1]) and torch.equal(s, out[0][0]), "the rendezvous changed a result"
+    n_diff = orc.check_topk(out[0][0].cpu().numpy(), out[0][1].cpu().numpy(), queries.astype(np.float64),
+                            rows.astype(np.float64), ids, k, rel_tol=1e-3)
+    assert n_diff <= max(2, (nq * k) // 500)
+eng.close()
+print("rendezvous ok")
+''' % ROOT
+    env = dict(os.environ)
+    env["ARTMIPS_DIAGNOSTICS"] = "1"
+    env["ARTMIPS_LIBRARY"] = os.path.join(ROOT, "art_amd", "lib", "libartmips_diag.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "rendezvous ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_stray_library_variable_is_ignored_without_the_opt_in():
     """`import art_amd` loads the shipped library unless BOTH ARTMIPS_DIAGNOSTICS=1 and ARTMIPS_LIBRARY
     are set (art_amd/_lib.py)."""
