@@ -891,11 +891,17 @@ static Plan make_plan(const Shard& s, int64_t n_rows, size_t row_bytes, int k, i
     // select time, and the expected survivors per query are k * sample_div whatever the shard size.
     // Minimising the sum gives sample_div = sqrt(c * n_tiles / (k * column groups per wave)) with
     // c = 0.45 for 1536-byte rows, fitted on shards of 2.6M..21M rows at k = 32 and 100
-    // (profiles/r01_o_sample_by_size.txt): 128 at 21M rows and k = 32, 48 on a 1/8 shard.
+    // (profiles/r01_o_sample_by_size.txt): 128 at 21M rows and k = 32, 48 on a 1/8 shard.  Since round 3
+    // c = 0.70 (60 on a 1/8 shard): the selection and the survivor path have become cheaper since the fit, and a
+    // coarser sample is 0.8 % faster on a 1/8 shard, 0.2-0.6 % on 8.8M-10.5M rows and in 16-query chunks, and
+    // changes nothing at 21M rows (clamped to 128) or in the gang launches (profiles/r03_h_sample_constant.txt;
+    // 1.4 is too much: the top-100 gangs then leave the two-part scan and lose 7 %).  fp32 rows of width 768 keep
+    // 0.45: their exact-f32 scan is MFMA-bound at any batch size and measured 2 % slower with the coarser sample.
     const double row_scale = (double)row_bytes / 1536.0;
     const double groups_per_wave = (double)nq * (double)nw / 4.0;
     long long sample_div = (long long)std::llround(
-        std::sqrt(0.45 * row_scale * (double)p.n_tiles / ((double)k * groups_per_wave)));
+        std::sqrt(0.01 * diag_int("ARTMIPS_SAMPLE_C100", row_bytes > 2048 ? 45 : 70) * row_scale * (double)p.n_tiles /
+                  ((double)k * groups_per_wave)));
     sample_div = std::min<long long>(128, std::max<long long>(16, sample_div));
     if (const int sd = diag_int("ARTMIPS_SAMPLE_DIV", 0)) sample_div = std::max(4, sd);
     const int staging_slots = STAGING_BYTES / (nw * 64 * nq * 8);
